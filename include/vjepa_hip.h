@@ -1,0 +1,142 @@
+/*
+ * vjepa_hip.h -- C ABI of libvjepa_hip.so: the MI355X (gfx950 / CDNA4) kernels of the V-JEPA pretraining step.
+ *
+ * The reference (facebookresearch/jepa) has no FFI layer: its device work is the ATen operator stream issued by
+ * app/vjepa/train.py:414-498 through src/models/*.  This header is the boundary a maintainer would bind instead of
+ * those ATen calls (see INTEGRATION.md for the ctypes stub).  Each entry point names the reference call site it
+ * replaces.  Conventions:
+ *   - every function returns 0 on success, a negative value for an argument error, or a positive hipError_t;
+ *     vj_last_error() returns a thread-local description.  No C++ exception crosses this boundary.
+ *   - all pointers are DEVICE pointers owned by the caller (borrowed for the duration of the launch);
+ *     the library never allocates, frees or retains them.  Workspaces are passed in (vj_*_ws_bytes()).
+ *   - every launch goes to the explicit hipStream_t (last argument); entry points are re-entrant.
+ *   - "bf16" buffers are raw bfloat16 bits (uint16_t); indices are int64 as produced by the reference collator
+ *     (src/masks/multiblock3d.py:155-203).
+ *   - no torch types appear here; PyTorch is only the allocator/stream provider on the host side.
+ */
+#ifndef VJEPA_HIP_H
+#define VJEPA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vj_stream_t; /* == hipStream_t */
+
+int vj_abi_version(void);
+const char* vj_last_error(void);
+
+/* ---- token-row movement (bit-exact) -------------------------------------------------------------------------
+ * apply_masks: torch.gather(x, 1, idx[..., None].repeat(1,1,D))            src/masks/utils.py:11-23
+ * dst[b,k,:] = src[b*src_batch_stride_rows + idx[b,k], :]; rows are row_bytes wide (multiple of 4).
+ * src_batch_stride_rows = N for a [B,N,D] source, 0 to broadcast a [1,N,D] table (predictor.py:199,214). */
+int vj_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t B, int64_t K, int64_t row_bytes,
+                   int64_t src_batch_stride_rows, vj_stream_t stream);
+/* backward of the gather (aten::gather_backward -> scatter_add_ into zeros; indices unique per sample):
+ * dst[B,N,row] is zero-filled, then dst[b, idx[b,k], :] = src[b,k,:]. */
+int vj_scatter_rows(const void* src, void* dst, const int64_t* idx, int64_t B, int64_t N, int64_t K,
+                    int64_t row_bytes, vj_stream_t stream);
+/* bf16 row-slice copy: dst[b, dst_off+j, :] = src[b, src_off+j, :], j < n  (x[:, N_ctxt:], predictor.py:236) */
+int vj_copy_rows(const void* src, void* dst, int64_t B, int64_t src_rows, int64_t src_off, int64_t dst_rows,
+                 int64_t dst_off, int64_t n, int64_t D, vj_stream_t stream);
+
+/* ---- tubelet PatchEmbed3D front end -------------------------------------------------------------------------
+ * Conv3d(3->D, k=s=(tub,p,p)) + flatten(2).transpose(1,2)                  src/models/utils/patch_embed.py:31-57
+ * is a GEMM over non-overlapping tubelets; this packs fp32 clips [B,C,T,H,W] into its bf16 A operand
+ * [B,K,C*tub*p*p] (element order c,dt,dh,dw = Conv3d weight order).  idx (nullable, [B,K]) fuses the context
+ * mask gather (only kept tubelets are packed); NULL packs all K = N tokens in (t,h,w) order. */
+int vj_tubelet_pack(const float* clips, void* out_bf16, const int64_t* idx, int64_t B, int64_t C, int64_t T,
+                    int64_t H, int64_t W, int64_t tubelet, int64_t patch, int64_t K, vj_stream_t stream);
+/* x += pos_embed (vision_transformer.py:172-174); with idx: x[b,k] += pos[idx[b,k]] (gather fused). */
+int vj_add_pos(void* x_bf16, const float* pos, const int64_t* idx, int64_t B, int64_t K, int64_t D,
+               vj_stream_t stream);
+
+/* ---- LayerNorm ----------------------------------------------------------------------------------------------
+ * nn.LayerNorm(eps=1e-6) (modules.py:97,106,115,119; vision_transformer.py:193; predictor.py:233).
+ * bf16 in/out, fp32 statistics; mean/rstd (nullable pair) are saved for the backward. */
+int vj_layernorm_fwd(const void* x_bf16, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                     float* rstd, int64_t rows, int64_t D, float eps, vj_stream_t stream);
+int64_t vj_layernorm_bwd_ws_bytes(int64_t D);
+/* dx = LN'(dy) [+ dres]; dgamma/dbeta = alpha*sum + beta_acc*old (fp32, into the gradient arena). */
+int vj_layernorm_bwd(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
+                     const float* rstd, const void* dres_bf16, void* dx_bf16, float* dgamma, float* dbeta,
+                     float alpha, float beta_acc, int64_t rows, int64_t D, void* ws, int64_t ws_bytes,
+                     vj_stream_t stream);
+
+/* ---- bf16 MFMA GEMM  C[M,N] = A[M,K] * B[N,K]^T (+ fused epilogue) ------------------------------------------
+ * nn.Linear fwd/bwd (modules.py:31-34,63,76; predictor.py:194,237) and the Conv3d GEMM (patch_embed.py:56).
+ * epilogue: 0 bf16 out = acc [+bias] [+residual]      (qkv / proj+residual / fc2+residual / dgrads)
+ *           1 bf16 out = gelu(acc+bias), aux_out(nullable) = acc+bias    (fc1 + nn.GELU, modules.py:31-32)
+ *           2 bf16 out = acc * gelu'(aux_in)           (fc2 dgrad fused with GELU backward)
+ *           3 fp32 out = alpha*acc + beta*C            (wgrad straight into the fp32 gradient arena)
+ * K % 32 == 0, N % 4 == 0, lda/ldb % 8 == 0.  flags bit0: register-staged operand path (A/B testing). */
+int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                    int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
+                    void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags,
+                    vj_stream_t stream);
+/* out[N, Mpad] = in[M,N]^T (zero padded): the wgrad operands dY^T, X^T; weight shadows W^T for dgrad. */
+int vj_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,
+                      vj_stream_t stream);
+/* bias / mask-token gradients: out[n] = alpha * sum_{m: row_lo <= m % group < row_hi} in[m][n] + beta*out[n] */
+int64_t vj_colsum_ws_bytes(int64_t N);
+int vj_colsum_bf16(const void* in, int64_t M, int64_t N, int64_t ld, int64_t group, int64_t row_lo, int64_t row_hi,
+                   float* out, float alpha, float beta, void* ws, int64_t ws_bytes, vj_stream_t stream);
+int vj_reduce_partials(const float* part, float* out, int64_t P, int64_t N, float alpha, float beta,
+                       vj_stream_t stream);
+
+/* ---- attention ----------------------------------------------------------------------------------------------
+ * F.scaled_dot_product_attention(q,k,v) (modules.py:66-69): dense, non-causal, scale = head_dim^-0.5.
+ * qkv: packed qkv-Linear output [B,S,3,H,hd] (modules.py:63 before the permute); o: [B,S,H*hd];
+ * lse2: [B,H,S] fp32 log2-sum-exp saved for the backward (nullable in inference).  hd % 8 == 0, hd <= 128. */
+int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd, float scale,
+                vj_stream_t stream);
+int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H);
+/* dqkv [B,S,3,H,hd] <- (dout [B,S,H*hd], saved qkv, o, lse2) */
+int vj_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B,
+                int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, vj_stream_t stream);
+
+/* ---- predictor token assembly (predictor.py:194-221) --------------------------------------------------------
+ * out[b, j<Ke] = embed[b,j] + pos[idx_e[b,j]];  out[b, Ke+j] = mask_token + pos[idx_p[b,j]] */
+int vj_pred_assemble_fwd(const void* e_bf16, const float* mask_token, const float* pos, const int64_t* idx_e,
+                         const int64_t* idx_p, void* out_bf16, int64_t B, int64_t Ke, int64_t Kp, int64_t D,
+                         vj_stream_t stream);
+
+/* ---- targets and loss (app/vjepa/train.py:419-459) ----------------------------------------------------------
+ * h[b,k,:] = F.layer_norm( norm(x)[b, idx[b,k], :] ), fp32 out: final encoder LayerNorm (eps_norm), the
+ * affine-free F.layer_norm (eps_ln = 1e-5, train.py:426) and apply_masks fused over the predicted rows only. */
+int vj_target_rows(const void* x_bf16, const float* gamma, const float* beta, const int64_t* idx, float* h,
+                   int64_t B, int64_t N, int64_t K, int64_t D, float eps_norm, float eps_ln, vj_stream_t stream);
+/* loss_out (+)= out_scale * sum(|z-h|^p / p); dz (nullable) = sign(z-h)|z-h|^(p-1) * gscale  (train.py:440-446) */
+int64_t vj_latent_loss_ws_bytes(void);
+int vj_latent_loss(const void* z_bf16, const float* h, void* dz_bf16, int64_t numel, float p, float gscale,
+                   float out_scale, int accumulate, float* loss_out, void* ws, int64_t ws_bytes,
+                   vj_stream_t stream);
+/* reg_fn (train.py:448-449,458): pstd[b,d] (+)= sqrt(var_k z[b,k,d] + 1e-4); reg = mean(relu(1 - pstd/n_masks)) */
+int vj_token_pstd(const void* z_bf16, float* pstd, int64_t B, int64_t K, int64_t D, int accumulate,
+                  vj_stream_t stream);
+int vj_reg_finish(const float* pstd_sum, int64_t n, int64_t n_masks, float* out, vj_stream_t stream);
+
+/* ---- parameter update over flat fp32 arenas (train.py:461-487; app/vjepa/utils.py:156-210) -------------------
+ * torch.optim.AdamW step (decoupled wd, bias correction from `step`), EMA of the target encoder
+ * (param_k = m*param_k + (1-m)*param_q, train.py:486-487) and the bf16 re-cast of both weight sets, one pass.
+ * p_bf16 / tgt / tgt_bf16 are nullable; gscale pre-multiplies the gradient (clip coefficient). n % 4 == 0. */
+int vj_adamw_ema(float* p, const float* g, float* exp_avg, float* exp_avg_sq, void* p_bf16, float* tgt,
+                 void* tgt_bf16, int64_t n, float lr, float wd, float beta1, float beta2, float eps, int64_t step,
+                 float gscale, float ema, vj_stream_t stream);
+int vj_ema_update(float* tgt, const float* src, void* tgt_bf16, int64_t n, float m, vj_stream_t stream);
+int vj_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, vj_stream_t stream);
+/* out2[0] (+)= sum g^2, out2[1] (+)= count of non-finite values  (clip_grad_norm_, GradScaler inf check) */
+int64_t vj_sqnorm_ws_bytes(void);
+int vj_sqnorm_f32(const float* g, int64_t n, float* out2, int accumulate, void* ws, int64_t ws_bytes,
+                  vj_stream_t stream);
+
+/* ---- hardware probes (tests / profiles only) ---------------------------------------------------------------- */
+int vj_probe_tr16(uint32_t* out256, int addr_scale, vj_stream_t stream);
+int vj_probe_copy(const void* src, void* dst, int64_t bytes, vj_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VJEPA_HIP_H */

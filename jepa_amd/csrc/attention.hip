@@ -1,0 +1,646 @@
+// Dense (non-causal, unmasked) multi-head attention over mask-gathered token sequences, forward and backward,
+// for gfx950.  Reference call site: F.scaled_dot_product_attention(q, k, v) in Attention.forward
+// (src/models/utils/modules.py:61-78); the `mask=` argument there is accepted and ignored, so "masked attention"
+// is dense attention over the shortened (gathered) sequence, with default scale head_dim**-0.5.
+//
+// q/k/v are read strided straight out of the packed qkv GEMM output [B, S, 3, H, hd] (no permute copies), the
+// output is written token-major [B, S, H*hd] ready for the proj GEMM; the backward writes dq/dk/dv packed as
+// dqkv [B, S, 3, H, hd] ready for the qkv dgrad/wgrad GEMMs.
+//
+// All three kernels compute TRANSPOSED products with MFMA 16x16x32 so that (i) softmax rows / per-query scalars
+// are lane-local (query = lane&15), (ii) the exponentiated scores feed the next MFMA straight from the
+// accumulator registers (the contraction index is permuted identically on both operands, so no cross-lane
+// movement), and (iii) every lane owns 4 consecutive head-dim columns of the result (8-byte stores).
+// K/V (or Q/dO) tiles of 64 rows are staged through LDS in two images: row-major with a 16-byte XOR swizzle
+// (ds_read_b128 fragments) and transposed [hd][64+8] (ds_read_b64 fragments for the operand whose contraction
+// index is the token).  The next tile's global loads are issued before the current tile's MFMAs.
+//
+// Softmax is computed in base 2: s2 = (q.k) * scale * log2(e); lse2 = max2 + log2(sum) is what the forward
+// saves for the backward (an internal format, produced and consumed only here).
+#include "common.hpp"
+
+#define VP 72  // transposed-image row pitch (elements): 64 tokens + 8 pad, 144 B keeps ds_read_b64 8-byte aligned
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  bf2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+template <int HDP>
+__device__ __forceinline__ int rm_swz(int row) {
+  return HDP >= 64 ? (row & 7) : 0;
+}
+
+// ---- row-major image: 64 rows x HDP, 16-byte chunks XOR-swizzled --------------------------------------------
+template <int HDP>
+struct RowTile {
+  static constexpr int CHP = HDP / 8;
+  static constexpr int NIT = (64 * CHP + 255) / 256;
+  static constexpr int BYTES = 64 * HDP * 2;
+  // base: pointer to element [row 0][col 0] of this (b,h) slice; rs: row stride in elements
+  static __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int64_t rs, int r0, int nrows, int hd,
+                                              int tid, u32x4_t* regs) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int item = tid + it * 256;
+      const int row = item / CHP, ch = item % CHP;
+      u32x4_t v = {0, 0, 0, 0};
+      if (item < 64 * CHP && r0 + row < nrows && ch * 8 < hd) v = *(const u32x4_t*)(base + (int64_t)(r0 + row) * rs + ch * 8);
+      regs[it] = v;
+    }
+  }
+  static __device__ __forceinline__ void store(char* lds, int tid, const u32x4_t* regs) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int item = tid + it * 256;
+      const int row = item / CHP, ch = item % CHP;
+      if (item < 64 * CHP) *(u32x4_t*)(lds + row * (HDP * 2) + ((ch ^ rm_swz<HDP>(row)) * 16)) = regs[it];
+    }
+  }
+  // MFMA fragment: 8 contiguous head-dim elements of row `row`, chunk index c
+  static __device__ __forceinline__ bf16x8_t frag(const char* lds, int row, int c) {
+    return *(const bf16x8_t*)(lds + row * (HDP * 2) + ((c ^ rm_swz<HDP>(row)) * 16));
+  }
+};
+
+// ---- transposed image: [HDP][VP], token index contiguous ----------------------------------------------------
+template <int HDP>
+struct ColTile {
+  static constexpr int CHP = HDP / 8;
+  static constexpr int NIT = (32 * CHP + 255) / 256;
+  static constexpr int BYTES = HDP * VP * 2;
+  static __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int64_t rs, int r0, int nrows, int hd,
+                                              int tid, u32x4_t (*regs)[2]) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int item = tid + it * 256;
+      const int kp = item & 31, ch = item >> 5;
+      u32x4_t v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+      if (item < 32 * CHP && ch * 8 < hd) {
+        const int ra = r0 + 2 * kp;
+        if (ra < nrows) v0 = *(const u32x4_t*)(base + (int64_t)ra * rs + ch * 8);
+        if (ra + 1 < nrows) v1 = *(const u32x4_t*)(base + (int64_t)(ra + 1) * rs + ch * 8);
+      }
+      regs[it][0] = v0;
+      regs[it][1] = v1;
+    }
+  }
+  static __device__ __forceinline__ void store(char* lds, int tid, const u32x4_t (*regs)[2]) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int item = tid + it * 256;
+      const int kp = item & 31, ch = item >> 5;
+      if (item < 32 * CHP) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const uint32_t a = regs[it][0][e >> 1], b = regs[it][1][e >> 1];
+          const uint32_t lo = (e & 1) ? (a >> 16) : (a & 0xffffu);
+          const uint32_t hi = (e & 1) ? (b & 0xffff0000u) : (b << 16);
+          *(uint32_t*)(lds + ((ch * 8 + e) * VP + 2 * kp) * 2) = lo | hi;
+        }
+      }
+    }
+  }
+  // MFMA fragment for the 32-token chunk c of column d: tokens {c*32+4g..+3, c*32+16+4g..+3}
+  static __device__ __forceinline__ bf16x8_t frag(const char* lds, int d, int c, int g) {
+    const u32x2_t lo = *(const u32x2_t*)(lds + (d * VP + c * 32 + 4 * g) * 2);
+    const u32x2_t hi = *(const u32x2_t*)(lds + (d * VP + c * 32 + 16 + 4 * g) * 2);
+    u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, w);
+  }
+};
+
+__device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* p, bool valid) {
+  u32x4_t v = {0, 0, 0, 0};
+  if (valid) v = *(const u32x4_t*)p;
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int qx = nblk >> 3, rx = nblk & 7, xcd = bid & 7, pos = bid >> 3;
+  return (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + pos;
+}
+
+// =============================================================================================================
+// forward:  O = softmax(Q K^T * scale) V,  128 queries per workgroup (32 per wave), 64-key tiles
+// =============================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                       float* __restrict__ lse2, int B, int S, int H, int hd,
+                                                       float sc, int nqb) {
+  __shared__ __attribute__((aligned(16))) char smem[RowTile<HDP>::BYTES + ColTile<HDP>::BYTES];
+  char* k_lds = smem;
+  char* vt_lds = smem + RowTile<HDP>::BYTES;
+  constexpr int KS = HDP / 32, DT = HDP / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = logical % nqb, bh = logical / nqb;
+  const int h = bh % H, b = bh / H;
+  const int64_t rs = (int64_t)3 * H * hd;
+  const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
+  const bf16_t* kbase = qbase + (int64_t)H * hd;
+  const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
+  const int q0 = qb * 128 + w * 32;
+
+  bf16x8_t qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int q = q0 + qt * 16 + li, d0 = ks * 32 + 8 * g;
+      qf[qt][ks] = load_frag_global(qbase + (int64_t)q * rs + d0, q < S && d0 < hd);
+    }
+
+  f32x4_t oacc[2][DT];
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) oacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+
+  u32x4_t kreg[RowTile<HDP>::NIT];
+  u32x4_t vreg[ColTile<HDP>::NIT][2];
+  const int nt = (S + 63) / 64;
+  RowTile<HDP>::load(kbase, rs, 0, S, hd, tid, kreg);
+  ColTile<HDP>::load(vbase, rs, 0, S, hd, tid, vreg);
+
+  for (int t = 0; t < nt; t++) {
+    const int k0 = t * 64;
+    __syncthreads();  // every wave is done with the previous tile's LDS image
+    RowTile<HDP>::store(k_lds, tid, kreg);
+    ColTile<HDP>::store(vt_lds, tid, vreg);
+    __syncthreads();
+    if (t + 1 < nt) {  // next tile's loads fly under this tile's MFMAs
+      RowTile<HDP>::load(kbase, rs, k0 + 64, S, hd, tid, kreg);
+      ColTile<HDP>::load(vbase, rs, k0 + 64, S, hd, tid, vreg);
+    }
+    // ---- S^T = K Q^T : sacc[qt][kt] holds S^T[key = kt*16 + 4g + r][q = li] ----
+    f32x4_t sacc[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++) sacc[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        const bf16x8_t kf = RowTile<HDP>::frag(k_lds, kt * 16 + li, ks * 4 + g);
+#pragma unroll
+        for (int qt = 0; qt < 2; qt++)
+          sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], sacc[qt][kt], 0, 0, 0);
+      }
+    // ---- online softmax (query = li, reduced over r, kt in-lane and over g across lanes 16/32 apart) ----
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int key = k0 + kt * 16 + 4 * g + r;
+          float s = sacc[qt][kt][r] * sc;
+          s = key < S ? s : -INFINITY;
+          sacc[qt][kt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float alpha = exp2f(mrun[qt] - mnew);
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float p = exp2f(sacc[qt][kt][r] - mnew);
+          sacc[qt][kt][r] = p;
+          ls += p;
+        }
+      lrun[qt] = lrun[qt] * alpha + ls;
+      mrun[qt] = mnew;
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) oacc[qt][dt] *= alpha;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        u32x4_t pw;
+        pw[0] = cvt_pk_bf16(sacc[qt][2 * c][0], sacc[qt][2 * c][1]);
+        pw[1] = cvt_pk_bf16(sacc[qt][2 * c][2], sacc[qt][2 * c][3]);
+        pw[2] = cvt_pk_bf16(sacc[qt][2 * c + 1][0], sacc[qt][2 * c + 1][1]);
+        pw[3] = cvt_pk_bf16(sacc[qt][2 * c + 1][2], sacc[qt][2 * c + 1][3]);
+        pf[qt][c] = __builtin_bit_cast(bf16x8_t, pw);
+      }
+    }
+    // ---- O^T += V^T P^T : oacc[qt][dt] holds O^T[d = dt*16 + 4g + r][q = li] ----
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const bf16x8_t vf = ColTile<HDP>::frag(vt_lds, dt * 16 + li, c, g);
+#pragma unroll
+        for (int qt = 0; qt < 2; qt++)
+          oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
+      }
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++) {
+    float l = lrun[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const int q = q0 + qt * 16 + li;
+    if (q < S) {
+      const float inv = 1.0f / l;
+      bf16_t* op = o + ((int64_t)b * S + q) * ((int64_t)H * hd) + (int64_t)h * hd;
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const int d = dt * 16 + 4 * g;
+        if (d < hd) {
+          u32x2_t ov;
+          ov[0] = cvt_pk_bf16(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv);
+          ov[1] = cvt_pk_bf16(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv);
+          *(u32x2_t*)(op + d) = ov;
+        }
+      }
+      if (g == 0 && lse2) lse2[((int64_t)b * H + h) * S + q] = mrun[qt] + log2f(l);
+    }
+  }
+}
+
+// =============================================================================================================
+// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]     (softmax-backward row term)
+// =============================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int64_t B, int S, int H, int hd) {
+  const int64_t total = B * S * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int h = (int)(i % H);
+    const int64_t bs = i / H;
+    const int s = (int)(bs % S);
+    const int64_t b = bs / S;
+    const bf16_t* op = o + i * hd;
+    const bf16_t* dp = dout + i * hd;
+    float acc = 0.f;
+    for (int d = 0; d < hd; d += 8) {
+      const u32x4_t a = *(const u32x4_t*)(op + d);
+      const u32x4_t c = *(const u32x4_t*)(dp + d);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc += bf_lo(a[j]) * bf_lo(c[j]) + bf_hi(a[j]) * bf_hi(c[j]);
+    }
+    delta[(b * H + h) * S + s] = acc;
+  }
+}
+
+// =============================================================================================================
+// backward, part 1: dK, dV.  One workgroup per 64-key block (16 keys per wave), loop over 64-query tiles.
+//   S = Q K^T (lane: S[q = qt*16+4g+r][key = li]),  P = exp2(S*sc - lse2[q]),  dP = dO V^T,
+//   dS = P (dP - delta[q]),  dV^T += dO^T P,  dK^T += Q^T dS  (then * scale)
+// =============================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv,
+                                                            const bf16_t* __restrict__ dout,
+                                                            const float* __restrict__ lse2,
+                                                            const float* __restrict__ delta,
+                                                            bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
+                                                            float sc, float scale, int nkb) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES + 2 * ColTile<HDP>::BYTES + 2 * 64 * 4];
+  char* q_lds = smem;
+  char* do_lds = smem + RowTile<HDP>::BYTES;
+  char* qt_lds = smem + 2 * RowTile<HDP>::BYTES;
+  char* dot_lds = qt_lds + ColTile<HDP>::BYTES;
+  float* lse_s = (float*)(dot_lds + ColTile<HDP>::BYTES);
+  float* dl_s = lse_s + 64;
+  constexpr int KS = HDP / 32, DT = HDP / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int kb = logical % nkb, bh = logical / nkb;
+  const int h = bh % H, b = bh / H;
+  const int64_t rs = (int64_t)3 * H * hd;
+  const int64_t os = (int64_t)H * hd;
+  const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
+  const bf16_t* kbase = qbase + (int64_t)H * hd;
+  const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
+  const bf16_t* dobase = dout + (int64_t)b * S * os + (int64_t)h * hd;
+  const float* lse_b = lse2 + ((int64_t)b * H + h) * S;
+  const float* dl_b = delta + ((int64_t)b * H + h) * S;
+  const int key = kb * 64 + w * 16 + li;
+  const bool key_ok = key < S;
+
+  bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    const int d0 = ks * 32 + 8 * g;
+    kf[ks] = load_frag_global(kbase + (int64_t)key * rs + d0, key_ok && d0 < hd);
+    vf[ks] = load_frag_global(vbase + (int64_t)key * rs + d0, key_ok && d0 < hd);
+  }
+  f32x4_t dvacc[DT], dkacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; dt++) {
+    dvacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    dkacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+
+  u32x4_t qreg[RowTile<HDP>::NIT], doreg[RowTile<HDP>::NIT];
+  u32x4_t qtreg[ColTile<HDP>::NIT][2], dotreg[ColTile<HDP>::NIT][2];
+  float lse_r = 0.f, dl_r = 0.f;
+  const int nt = (S + 63) / 64;
+  auto load_tile = [&](int r0) {
+    RowTile<HDP>::load(qbase, rs, r0, S, hd, tid, qreg);
+    RowTile<HDP>::load(dobase, os, r0, S, hd, tid, doreg);
+    ColTile<HDP>::load(qbase, rs, r0, S, hd, tid, qtreg);
+    ColTile<HDP>::load(dobase, os, r0, S, hd, tid, dotreg);
+    if (tid < 64) {
+      const int q = r0 + tid;
+      lse_r = q < S ? lse_b[q] : INFINITY;  // +inf -> P = 0 for padded query rows
+      dl_r = q < S ? dl_b[q] : 0.f;
+    }
+  };
+  load_tile(0);
+
+  for (int t = 0; t < nt; t++) {
+    __syncthreads();
+    RowTile<HDP>::store(q_lds, tid, qreg);
+    RowTile<HDP>::store(do_lds, tid, doreg);
+    ColTile<HDP>::store(qt_lds, tid, qtreg);
+    ColTile<HDP>::store(dot_lds, tid, dotreg);
+    if (tid < 64) {
+      lse_s[tid] = lse_r;
+      dl_s[tid] = dl_r;
+    }
+    __syncthreads();
+    if (t + 1 < nt) load_tile((t + 1) * 64);
+
+    float pv[4][4], dsv[4][4];
+#pragma unroll
+    for (int qt = 0; qt < 4; qt++) {
+      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        const bf16x8_t qa = RowTile<HDP>::frag(q_lds, qt * 16 + li, ks * 4 + g);
+        const bf16x8_t da = RowTile<HDP>::frag(do_lds, qt * 16 + li, ks * 4 + g);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int q = qt * 16 + 4 * g + r;
+        float p = exp2f(sacc[r] * sc - lse_s[q]);
+        p = key_ok ? p : 0.f;
+        pv[qt][r] = p;
+        dsv[qt][r] = p * (dpacc[r] - dl_s[q]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      u32x4_t pw, dw;
+      pw[0] = cvt_pk_bf16(pv[2 * c][0], pv[2 * c][1]);
+      pw[1] = cvt_pk_bf16(pv[2 * c][2], pv[2 * c][3]);
+      pw[2] = cvt_pk_bf16(pv[2 * c + 1][0], pv[2 * c + 1][1]);
+      pw[3] = cvt_pk_bf16(pv[2 * c + 1][2], pv[2 * c + 1][3]);
+      dw[0] = cvt_pk_bf16(dsv[2 * c][0], dsv[2 * c][1]);
+      dw[1] = cvt_pk_bf16(dsv[2 * c][2], dsv[2 * c][3]);
+      dw[2] = cvt_pk_bf16(dsv[2 * c + 1][0], dsv[2 * c + 1][1]);
+      dw[3] = cvt_pk_bf16(dsv[2 * c + 1][2], dsv[2 * c + 1][3]);
+      const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, pw);
+      const bf16x8_t dfr = __builtin_bit_cast(bf16x8_t, dw);
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const bf16x8_t dot_f = ColTile<HDP>::frag(dot_lds, dt * 16 + li, c, g);
+        const bf16x8_t qt_f = ColTile<HDP>::frag(qt_lds, dt * 16 + li, c, g);
+        dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr, dvacc[dt], 0, 0, 0);
+        dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dfr, dkacc[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  if (key_ok) {
+    bf16_t* dkp = dqkv + ((int64_t)b * S + key) * rs + (int64_t)H * hd + (int64_t)h * hd;
+    bf16_t* dvp = dkp + (int64_t)H * hd;
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+      const int d = dt * 16 + 4 * g;
+      if (d < hd) {
+        u32x2_t a, c;
+        a[0] = cvt_pk_bf16(dkacc[dt][0] * scale, dkacc[dt][1] * scale);
+        a[1] = cvt_pk_bf16(dkacc[dt][2] * scale, dkacc[dt][3] * scale);
+        c[0] = cvt_pk_bf16(dvacc[dt][0], dvacc[dt][1]);
+        c[1] = cvt_pk_bf16(dvacc[dt][2], dvacc[dt][3]);
+        *(u32x2_t*)(dkp + d) = a;
+        *(u32x2_t*)(dvp + d) = c;
+      }
+    }
+  }
+}
+
+// =============================================================================================================
+// backward, part 2: dQ.  One workgroup per 128 queries (32 per wave), loop over 64-key tiles.
+//   S^T = K Q^T, dP^T = V dO^T (lane: [key = kt*16+4g+r][q = li]),  dS^T = P^T (dP^T - delta[q]),
+//   dQ^T += K^T dS^T  (then * scale)
+// =============================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
+                                                          const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse2,
+                                                          const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
+                                                          float sc, float scale, int nqb) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES + ColTile<HDP>::BYTES];
+  char* k_lds = smem;
+  char* v_lds = smem + RowTile<HDP>::BYTES;
+  char* kt_lds = smem + 2 * RowTile<HDP>::BYTES;
+  constexpr int KS = HDP / 32, DT = HDP / 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = logical % nqb, bh = logical / nqb;
+  const int h = bh % H, b = bh / H;
+  const int64_t rs = (int64_t)3 * H * hd;
+  const int64_t os = (int64_t)H * hd;
+  const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
+  const bf16_t* kbase = qbase + (int64_t)H * hd;
+  const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
+  const bf16_t* dobase = dout + (int64_t)b * S * os + (int64_t)h * hd;
+  const int q0 = qb * 128 + w * 32;
+
+  bf16x8_t qf[2][KS], dof[2][KS];
+  float lse_q[2], dl_q[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++) {
+    const int q = q0 + qt * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int d0 = ks * 32 + 8 * g;
+      qf[qt][ks] = load_frag_global(qbase + (int64_t)q * rs + d0, q < S && d0 < hd);
+      dof[qt][ks] = load_frag_global(dobase + (int64_t)q * os + d0, q < S && d0 < hd);
+    }
+    lse_q[qt] = q < S ? lse2[((int64_t)b * H + h) * S + q] : INFINITY;
+    dl_q[qt] = q < S ? delta[((int64_t)b * H + h) * S + q] : 0.f;
+  }
+  f32x4_t dqacc[2][DT];
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) dqacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t kreg[RowTile<HDP>::NIT], vreg[RowTile<HDP>::NIT];
+  u32x4_t ktreg[ColTile<HDP>::NIT][2];
+  const int nt = (S + 63) / 64;
+  RowTile<HDP>::load(kbase, rs, 0, S, hd, tid, kreg);
+  RowTile<HDP>::load(vbase, rs, 0, S, hd, tid, vreg);
+  ColTile<HDP>::load(kbase, rs, 0, S, hd, tid, ktreg);
+
+  for (int t = 0; t < nt; t++) {
+    const int k0 = t * 64;
+    __syncthreads();
+    RowTile<HDP>::store(k_lds, tid, kreg);
+    RowTile<HDP>::store(v_lds, tid, vreg);
+    ColTile<HDP>::store(kt_lds, tid, ktreg);
+    __syncthreads();
+    if (t + 1 < nt) {
+      RowTile<HDP>::load(kbase, rs, k0 + 64, S, hd, tid, kreg);
+      RowTile<HDP>::load(vbase, rs, k0 + 64, S, hd, tid, vreg);
+      ColTile<HDP>::load(kbase, rs, k0 + 64, S, hd, tid, ktreg);
+    }
+    f32x4_t sacc[2][4], dpacc[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++) {
+        sacc[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        dpacc[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        const bf16x8_t ka = RowTile<HDP>::frag(k_lds, kt * 16 + li, ks * 4 + g);
+        const bf16x8_t va = RowTile<HDP>::frag(v_lds, kt * 16 + li, ks * 4 + g);
+#pragma unroll
+        for (int qt = 0; qt < 2; qt++) {
+          sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qt][ks], sacc[qt][kt], 0, 0, 0);
+          dpacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qt][ks], dpacc[qt][kt], 0, 0, 0);
+        }
+      }
+    bf16x8_t dsf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int key = k0 + kt * 16 + 4 * g + r;
+          float p = exp2f(sacc[qt][kt][r] * sc - lse_q[qt]);
+          p = key < S ? p : 0.f;
+          sacc[qt][kt][r] = p * (dpacc[qt][kt][r] - dl_q[qt]);
+        }
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        u32x4_t dw;
+        dw[0] = cvt_pk_bf16(sacc[qt][2 * c][0], sacc[qt][2 * c][1]);
+        dw[1] = cvt_pk_bf16(sacc[qt][2 * c][2], sacc[qt][2 * c][3]);
+        dw[2] = cvt_pk_bf16(sacc[qt][2 * c + 1][0], sacc[qt][2 * c + 1][1]);
+        dw[3] = cvt_pk_bf16(sacc[qt][2 * c + 1][2], sacc[qt][2 * c + 1][3]);
+        dsf[qt][c] = __builtin_bit_cast(bf16x8_t, dw);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const bf16x8_t ktf = ColTile<HDP>::frag(kt_lds, dt * 16 + li, c, g);
+#pragma unroll
+        for (int qt = 0; qt < 2; qt++)
+          dqacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt][c], dqacc[qt][dt], 0, 0, 0);
+      }
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++) {
+    const int q = q0 + qt * 16 + li;
+    if (q < S) {
+      bf16_t* dqp = dqkv + ((int64_t)b * S + q) * rs + (int64_t)h * hd;
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const int d = dt * 16 + 4 * g;
+        if (d < hd) {
+          u32x2_t a;
+          a[0] = cvt_pk_bf16(dqacc[qt][dt][0] * scale, dqacc[qt][dt][1] * scale);
+          a[1] = cvt_pk_bf16(dqacc[qt][dt][2] * scale, dqacc[qt][dt][3] * scale);
+          *(u32x2_t*)(dqp + d) = a;
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================================
+// host entry points
+// =============================================================================================================
+static int pick_hdp(int64_t hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : (hd <= 128 ? 128 : 0)); }
+#define LOG2E 1.4426950408889634f
+
+extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd,
+                           float scale, hipStream_t stream) {
+  VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_fwd: head_dim=%ld unsupported (need %%8==0, <=128)", (long)hd);
+  VJ_CHECK_ARG(B >= 0 && S >= 0 && H > 0, "vj_attn_fwd: bad dims");
+  if (B * S == 0) return 0;
+  const int nqb = (int)cdiv64(S, 128);
+  const int64_t nblk = B * H * nqb;
+  VJ_CHECK_ARG(nblk < (1ll << 31), "vj_attn_fwd: grid too large");
+  const float sc = scale * LOG2E;
+  switch (pick_hdp(hd)) {
+    case 32:
+      hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)qkv,
+                         (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb);
+      break;
+    case 64:
+      hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)qkv,
+                         (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb);
+      break;
+    default:
+      hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)qkv,
+                         (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb);
+  }
+  VJ_LAUNCH_CHECK("vj_attn_fwd");
+  return 0;
+}
+
+extern "C" int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H) { return B * S * H * 4; }
+
+extern "C" int vj_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv,
+                           int64_t B, int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes,
+                           hipStream_t stream) {
+  VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_bwd: head_dim=%ld unsupported", (long)hd);
+  VJ_CHECK_ARG(ws_bytes >= vj_attn_bwd_ws_bytes(B, S, H), "vj_attn_bwd: workspace too small");
+  if (B * S == 0) return 0;
+  float* delta = (float*)ws;
+  {
+    int64_t gsz = cdiv64(B * S * H, 256);
+    if (gsz > 256 * 16) gsz = 256 * 16;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)gsz), dim3(256), 0, stream, (const bf16_t*)o,
+                       (const bf16_t*)dout, delta, B, (int)S, (int)H, (int)hd);
+    VJ_LAUNCH_CHECK("vj_attn_bwd(delta)");
+  }
+  const int nkb = (int)cdiv64(S, 64), nqb = (int)cdiv64(S, 128);
+  const int64_t g1 = B * H * nkb, g2 = B * H * nqb;
+  VJ_CHECK_ARG(g1 < (1ll << 31), "vj_attn_bwd: grid too large");
+  const float sc = scale * LOG2E;
+#define VJ_BWD_LAUNCH(HDPV)                                                                                        \
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HDPV>, dim3((unsigned)g1), dim3(256), 0, stream, (const bf16_t*)qkv,     \
+                     (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H, (int)hd, sc, scale,   \
+                     nkb);                                                                                         \
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<HDPV>, dim3((unsigned)g2), dim3(256), 0, stream, (const bf16_t*)qkv,       \
+                     (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H, (int)hd, sc, scale,   \
+                     nqb);
+  switch (pick_hdp(hd)) {
+    case 32: VJ_BWD_LAUNCH(32); break;
+    case 64: VJ_BWD_LAUNCH(64); break;
+    default: VJ_BWD_LAUNCH(128);
+  }
+#undef VJ_BWD_LAUNCH
+  VJ_LAUNCH_CHECK("vj_attn_bwd");
+  return 0;
+}

@@ -1,0 +1,73 @@
+// Shared device/host helpers for the V-JEPA gfx950 kernels.
+// Everything here is CDNA4-only (wave64, MFMA, LDS-DMA); there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in HBM
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define VJ_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved: identical to torch's float -> bfloat16
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// two fp32 -> packed bf16x2 (RNE); lowers to one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+  bf2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU and its derivative: nn.GELU() default in the reference (modules.py:32)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- host side error plumbing (no C++ exception crosses the C ABI) ----
+extern "C" const char* vj_last_error(void);
+void vj_set_error(const char* fmt, ...);
+
+#define VJ_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      vj_set_error(__VA_ARGS__);           \
+      return -1;                           \
+    }                                      \
+  } while (0)
+
+#define VJ_LAUNCH_CHECK(name)                                              \
+  do {                                                                     \
+    hipError_t _e = hipGetLastError();                                     \
+    if (_e != hipSuccess) {                                                \
+      vj_set_error("%s: launch failed: %s", name, hipGetErrorString(_e)); \
+      return (int)_e;                                                      \
+    }                                                                      \
+  } while (0)
+
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,12 @@
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.hpp"
+static thread_local char g_err[512] = "";
+void vj_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* vj_last_error(void) { return g_err; }
+extern "C" int vj_abi_version(void) { return 1; }

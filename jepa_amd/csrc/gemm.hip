@@ -1,0 +1,274 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] * B[N,K]^T   (both operands K-contiguous, fp32 accumulate)
+//
+// This one core serves every Linear of the V-JEPA step (reference: nn.Linear call sites modules.py:31-34,63,76;
+// predictor.py:194,237; Conv3d patch embed patch_embed.py:56 after tubelet packing):
+//   fwd    Y  = X  * W^T            A = X  [M,K],      B = W   [N,K]
+//   dgrad  dX = dY * W              A = dY [M,N],      B = W^T [K,N]   (bf16 transposed weight shadow)
+//   wgrad  dW = dY^T * X            A = dY^T [N,Mpad], B = X^T [K,Mpad] -> fp32 straight into the grad arena
+//
+// Structure: 128x128 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles; K-tile 64 (32 as a
+// fallback when K % 64 != 0); two LDS buffers; ONE barrier per K-tile; tile t+1 is staged while tile t is
+// multiplied.  Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip) with the XOR swizzle applied on the
+// per-lane SOURCE address (the DMA destination is lane-linear), or register staging (same LDS image) when the
+// caller asks for it.  The MFMA is issued with swapped operands (D = Bfrag x Afrag) so each lane owns four
+// CONSECUTIVE output columns: 8-byte bf16 / 16-byte fp32 epilogue accesses for C, bias, residual and aux.
+// Workgroup ids are remapped so every XCD (private L2) works on a contiguous band of tiles.
+#include "common.hpp"
+
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_F32 = 3 };
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;      // [N] fp32, nullable
+  const bf16_t* res;      // [M,N] bf16 residual, nullable (EPI_BF16)
+  const bf16_t* aux_in;   // [M,N] bf16 pre-activation u (EPI_DGELU)
+  bf16_t* aux_out;        // [M,N] bf16 pre-activation u out, nullable (EPI_GELU)
+  int64_t M, N, K, lda, ldb, ldc, ldr, ldaux;
+  float alpha, beta;
+  int tiles_m, tiles_n;
+};
+
+#define BM 128
+#define BN 128
+
+template <int BK>
+__device__ __forceinline__ int swz_of(int row) {
+  return BK == 64 ? (row & 7) : 0;
+}
+
+// ---- staging: one 128 x BK bf16 operand tile -> LDS (lane-linear image, source-side swizzle) ----
+template <int BK, bool GLDS>
+__device__ __forceinline__ void stage_issue(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t rows,
+                                            int64_t k0, char* lds_tile, int tid, int wave_u, u32x4_t* regs) {
+  constexpr int CPR = BK / 8;                  // 16-byte chunks per tile row
+  constexpr int NIT = (128 * CPR) / 256;       // chunks per thread
+#pragma unroll
+  for (int j = 0; j < NIT; j++) {
+    const int q = j * 256 + tid;
+    const int row = q / CPR, cpos = q % CPR;
+    const int c = cpos ^ swz_of<BK>(row);
+    int64_t gr = row0 + row;
+    gr = gr < rows ? gr : rows - 1;            // clamp: tail rows are never stored
+    const bf16_t* src = G + gr * ld + k0 + c * 8;
+    if constexpr (GLDS) {
+      char* dst = lds_tile + (j * 256 + wave_u * 64) * 16;  // wave-uniform base; HW adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    } else {
+      regs[j] = *(const u32x4_t*)src;
+    }
+  }
+}
+
+template <int BK>
+__device__ __forceinline__ void stage_commit(char* lds_tile, int tid, const u32x4_t* regs) {
+  constexpr int CPR = BK / 8;
+  constexpr int NIT = (128 * CPR) / 256;
+#pragma unroll
+  for (int j = 0; j < NIT; j++) {
+    const int q = j * 256 + tid;
+    *(u32x4_t*)(lds_tile + q * 16) = regs[j];
+  }
+}
+
+template <int BK, int EPI, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE_BYTES = 128 * BK * 2;
+  constexpr int CPR = BK / 8;
+  constexpr int NIT = (128 * CPR) / 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_u >> 1, wn = wave_u & 1;
+
+  // ---- XCD-aware, grouped tile mapping (bijective for any grid size) ----
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int qx = nblk >> 3, rx = nblk & 7, xcd = bid & 7, pos = bid >> 3;
+  const int logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + pos;
+  constexpr int GM = 8;
+  const int per_group = GM * p.tiles_n;
+  const int group = logical / per_group, in_g = logical - group * per_group;
+  const int first_m = group * GM;
+  const int gsz = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+  const int tm = first_m + in_g % gsz, tn = in_g / gsz;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (int)(p.K / BK);
+  u32x4_t ra[NIT], rb[NIT];
+
+  // fragment read offsets (bytes inside a tile), constant across K-tiles
+  const int frow = lane & 15, fg = lane >> 4;
+  int a_off[4][BK / 32], b_off[4][BK / 32];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ks++) {
+      const int ra_ = wm * 64 + i * 16 + frow, rb_ = wn * 64 + i * 16 + frow;
+      const int c = ks * 4 + fg;
+      a_off[i][ks] = ra_ * (BK * 2) + ((c ^ swz_of<BK>(ra_)) * 16);
+      b_off[i][ks] = rb_ * (BK * 2) + ((c ^ swz_of<BK>(rb_)) * 16);
+    }
+
+  // prologue: stage tile 0 into buffer 0
+  stage_issue<BK, GLDS>(p.A, p.lda, m0, p.M, 0, smem, tid, wave_u, ra);
+  stage_issue<BK, GLDS>(p.B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, tid, wave_u, rb);
+  if constexpr (!GLDS) {
+    stage_commit<BK>(smem, tid, ra);
+    stage_commit<BK>(smem + TILE_BYTES, tid, rb);
+  }
+
+  for (int kt = 0; kt < nk; kt++) {
+    char* cur = smem + (kt & 1) * (2 * TILE_BYTES);
+    char* nxt = smem + ((kt + 1) & 1) * (2 * TILE_BYTES);
+    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt is in LDS for every wave; every wave is done reading tile kt-1
+    if (kt + 1 < nk) {
+      stage_issue<BK, GLDS>(p.A, p.lda, m0, p.M, (int64_t)(kt + 1) * BK, nxt, tid, wave_u, ra);
+      stage_issue<BK, GLDS>(p.B, p.ldb, n0, p.N, (int64_t)(kt + 1) * BK, nxt + TILE_BYTES, tid, wave_u, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ks++) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        af[i] = *(const bf16x8_t*)(cur + a_off[i][ks]);
+        bfr[i] = *(const bf16x8_t*)(cur + TILE_BYTES + b_off[i][ks]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (!GLDS) {
+      if (kt + 1 < nk) {  // other buffer: nobody reads it until the next barrier
+        stage_commit<BK>(nxt, tid, ra);
+        stage_commit<BK>(nxt + TILE_BYTES, tid, rb);
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns rows m = .. + (lane&15), columns n = .. + 4*(lane>>4) + {0,1,2,3} ----
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int64_t m = m0 + wm * 64 + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t n = n0 + wn * 64 + j * 16 + fg * 4;
+      if (n >= p.N) continue;  // N % 4 == 0 is enforced by the host wrapper
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if constexpr (EPI == EPI_F32) {
+        float* cp = (float*)p.C + m * p.ldc + n;
+        float4 o = make_float4(v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha);
+        if (p.beta != 0.f) {
+          const float4 c0 = *(const float4*)cp;
+          o.x += p.beta * c0.x;
+          o.y += p.beta * c0.y;
+          o.z += p.beta * c0.z;
+          o.w += p.beta * c0.w;
+        }
+        *(float4*)cp = o;
+      } else {
+        if (p.bias) {
+          const float4 b4 = *(const float4*)(p.bias + n);
+          v[0] += b4.x;
+          v[1] += b4.y;
+          v[2] += b4.z;
+          v[3] += b4.w;
+        }
+        if constexpr (EPI == EPI_GELU) {
+          u32x2_t u;
+          u[0] = pack_bf2(v[0], v[1]);
+          u[1] = pack_bf2(v[2], v[3]);
+          if (p.aux_out) *(u32x2_t*)(p.aux_out + m * p.ldaux + n) = u;
+          // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
+          v[0] = gelu_f(bf_lo(u[0]));
+          v[1] = gelu_f(bf_hi(u[0]));
+          v[2] = gelu_f(bf_lo(u[1]));
+          v[3] = gelu_f(bf_hi(u[1]));
+        } else if constexpr (EPI == EPI_DGELU) {
+          const u32x2_t u = *(const u32x2_t*)(p.aux_in + m * p.ldaux + n);
+          v[0] *= dgelu_f(bf_lo(u[0]));
+          v[1] *= dgelu_f(bf_hi(u[0]));
+          v[2] *= dgelu_f(bf_lo(u[1]));
+          v[3] *= dgelu_f(bf_hi(u[1]));
+        } else {
+          if (p.res) {
+            const u32x2_t r2 = *(const u32x2_t*)(p.res + m * p.ldr + n);
+            v[0] += bf_lo(r2[0]);
+            v[1] += bf_hi(r2[0]);
+            v[2] += bf_lo(r2[1]);
+            v[3] += bf_hi(r2[1]);
+          }
+        }
+        u32x2_t o;
+        o[0] = pack_bf2(v[0], v[1]);
+        o[1] = pack_bf2(v[2], v[3]);
+        *(u32x2_t*)((bf16_t*)p.C + m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+template <int BK, int EPI, bool GLDS>
+static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  constexpr int smem = 2 * 2 * 128 * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, EPI, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const int nblk = a.tiles_m * a.tiles_n;
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, EPI, GLDS>), dim3(nblk), dim3(256), smem, stream, a);
+  VJ_LAUNCH_CHECK("vj_gemm_bf16_nt");
+  return 0;
+}
+
+template <int EPI>
+static int dispatch_gemm(const GemmArgs& a, int flags, hipStream_t stream) {
+  const bool reg_staged = (flags & 1) != 0;
+  if (a.K % 64 == 0) return reg_staged ? launch_gemm<64, EPI, false>(a, stream) : launch_gemm<64, EPI, true>(a, stream);
+  return reg_staged ? launch_gemm<32, EPI, false>(a, stream) : launch_gemm<32, EPI, true>(a, stream);
+}
+
+// flags: bit0 = register-staged operand path instead of LDS-DMA (same numerics; for A/B testing)
+extern "C" int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                               int64_t M, int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr,
+                               const void* aux_in, void* aux_out, int64_t ldaux, int epilogue, float alpha,
+                               float beta, int flags, hipStream_t stream) {
+  VJ_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "vj_gemm_bf16_nt: negative dim");
+  if (M == 0 || N == 0) return 0;
+  VJ_CHECK_ARG(K > 0 && K % 32 == 0, "vj_gemm_bf16_nt: K=%ld must be a positive multiple of 32 (pad the operands)", (long)K);
+  VJ_CHECK_ARG(N % 4 == 0, "vj_gemm_bf16_nt: N=%ld must be a multiple of 4", (long)N);
+  VJ_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K,
+               "vj_gemm_bf16_nt: lda/ldb must be multiples of 8 and >= K (lda=%ld ldb=%ld K=%ld)", (long)lda,
+               (long)ldb, (long)K);
+  VJ_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "vj_gemm_bf16_nt: A/B must be 16-byte aligned");
+  VJ_CHECK_ARG(ldc % 4 == 0 && ldc >= N, "vj_gemm_bf16_nt: ldc=%ld must be a multiple of 4 and >= N", (long)ldc);
+  VJ_CHECK_ARG(epilogue >= EPI_BF16 && epilogue <= EPI_F32, "vj_gemm_bf16_nt: unknown epilogue %d", epilogue);
+  VJ_CHECK_ARG((uintptr_t)C % (epilogue == EPI_F32 ? 16 : 8) == 0, "vj_gemm_bf16_nt: C misaligned");
+  if (epilogue == EPI_DGELU) VJ_CHECK_ARG(aux_in != nullptr && ldaux % 4 == 0, "vj_gemm_bf16_nt: EPI_DGELU needs aux_in");
+  if (residual) VJ_CHECK_ARG(epilogue == EPI_BF16 && ldr % 4 == 0, "vj_gemm_bf16_nt: residual only with EPI_BF16");
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = bias; a.res = (const bf16_t*)residual;
+  a.aux_in = (const bf16_t*)aux_in; a.aux_out = (bf16_t*)aux_out;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
+  a.alpha = alpha; a.beta = beta;
+  a.tiles_m = (int)cdiv64(M, BM); a.tiles_n = (int)cdiv64(N, BN);
+  switch (epilogue) {
+    case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, stream);
+    case EPI_GELU: return dispatch_gemm<EPI_GELU>(a, flags, stream);
+    case EPI_DGELU: return dispatch_gemm<EPI_DGELU>(a, flags, stream);
+    default: return dispatch_gemm<EPI_F32>(a, flags, stream);
+  }
+}

@@ -1,0 +1,453 @@
+// LayerNorm forward/backward (row per wave, fp32 statistics), the fused target path
+// h = F.layer_norm(norm(x))[masks_pred] and the latent L_p loss of the V-JEPA step.
+//
+// Reference behaviour restated (never copied):
+//   nn.LayerNorm(eps=1e-6) in every Block / final norm   src/models/vision_transformer.py:252-281, modules.py:97,106
+//   h = F.layer_norm(target_encoder(c)) ; apply_masks    app/vjepa/train.py:424-428
+//   loss_fn: mean(|z-h|^p)/p averaged over masks         app/vjepa/train.py:440-446
+//   reg_fn : sqrt(var_tokens(z)+1e-4)                    app/vjepa/train.py:448-449,458
+#include "common.hpp"
+
+int vj_reduce_partials_strided(const float* part, float* out, int64_t P, int64_t N, int64_t stride, float alpha,
+                               float beta, hipStream_t stream);
+
+#define LN_MAX_CHUNKS 4  // D <= 2048, D % 8 == 0: each lane owns up to 4 chunks of 8 columns
+
+__device__ __forceinline__ void load8(const bf16_t* p, float* v) {
+  const u32x4_t w = *(const u32x4_t*)p;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    v[2 * i] = bf_lo(w[i]);
+    v[2 * i + 1] = bf_hi(w[i]);
+  }
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float* v) {
+  u32x4_t w;
+#pragma unroll
+  for (int i = 0; i < 4; i++) w[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+  *(u32x4_t*)p = w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layernorm_fwd: y = (x-mean)*rstd*gamma + beta  (bf16 in, bf16 out, fp32 math, biased variance)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const float invD = 1.0f / (float)D;
+  for (int64_t r = wave; r < rows; r += nw) {
+    const bf16_t* xp = x + r * D;
+    float v[LN_MAX_CHUNKS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+        load8(xp + c, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[i][j];
+      }
+    }
+    const float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float d = v[i][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+    bf16_t* yp = y + r * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mean) * rstd * gamma[c + j] + beta[c + j];
+        store8(yp + c, o);
+      }
+    }
+    if (lane == 0 && mean_out) {
+      mean_out[r] = mean;
+      rstd_out[r] = rstd;
+    }
+  }
+}
+
+static inline int ln_grid(int64_t rows) {
+  int64_t g = cdiv64(rows, 4);
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int vj_layernorm_fwd(const void* x_bf16, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                                float* rstd, int64_t rows, int64_t D, float eps, hipStream_t stream) {
+  VJ_CHECK_ARG(D % 8 == 0 && D <= 512 * LN_MAX_CHUNKS, "vj_layernorm_fwd: D=%ld unsupported (need D%%8==0, D<=%d)",
+               (long)D, 512 * LN_MAX_CHUNKS);
+  VJ_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "vj_layernorm_fwd: mean and rstd must both be given or both null");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ln_grid(rows)), dim3(256), 0, stream, (const bf16_t*)x_bf16, gamma,
+                     beta, (bf16_t*)y_bf16, mean, rstd, rows, (int)D, eps);
+  VJ_LAUNCH_CHECK("vj_layernorm_fwd");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layernorm_bwd: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres], g = dy*gamma
+// per-block partial dgamma/dbeta in fp32 -> part[blk][0:D]=dgamma, part[blk][D:2D]=dbeta
+// ---------------------------------------------------------------------------------------------
+#define LN_BWD_BLOCKS 128
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in,
+                                                            const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                                            float* __restrict__ part, int64_t rows, int D) {
+  __shared__ float red[4][2 * 512 * LN_MAX_CHUNKS / 4];  // 4 waves x (dgamma|dbeta) staged per chunk pass
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float invD = 1.0f / (float)D;
+  float ag[LN_MAX_CHUNKS][8], ab[LN_MAX_CHUNKS][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) ag[i][j] = ab[i][j] = 0.f;
+
+  const int64_t rows_per = cdiv64(rows, gridDim.x);
+  const int64_t rbeg = (int64_t)blockIdx.x * rows_per;
+  const int64_t rend = (rbeg + rows_per < rows) ? rbeg + rows_per : rows;
+  for (int64_t r = rbeg + wv; r < rend; r += 4) {
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    float xh[LN_MAX_CHUNKS][8], g[LN_MAX_CHUNKS][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+        float xv[8], dv[8];
+        load8(x + r * D + c, xv);
+        load8(dy + r * D + c, dv);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          xh[i][j] = (xv[j] - mean) * rstd;
+          g[i][j] = dv[j] * gamma[c + j];
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+          ag[i][j] += dv[j] * xh[i][j];
+          ab[i][j] += dv[j];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+        float o[8];
+        if (dres) {
+          load8(dres + r * D + c, o);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) o[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] += rstd * (g[i][j] - c1 - xh[i][j] * c2);
+        store8(dx + r * D + c, o);
+      }
+    }
+  }
+  // cross-wave reduction of the column partials, one chunk pass at a time (512 columns x {dgamma,dbeta})
+  float* pg = part + (int64_t)blockIdx.x * 2 * D;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+    if (i * 512 < D) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        red[wv][lane * 8 + j] = ag[i][j];
+        red[wv][512 + lane * 8 + j] = ab[i][j];
+      }
+      __syncthreads();
+      for (int q = threadIdx.x; q < 1024; q += 256) {
+        const int col = (q & 511) + i * 512;
+        if (col < D) {
+          const float s = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+          pg[(q >> 9) * D + col] = s;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int64_t vj_layernorm_bwd_ws_bytes(int64_t D) { return (int64_t)LN_BWD_BLOCKS * 2 * D * 4; }
+
+// dgamma/dbeta: out = alpha * sum + beta_acc * out   (beta_acc = 1 accumulates across calls)
+extern "C" int vj_layernorm_bwd(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
+                                const float* rstd, const void* dres_bf16, void* dx_bf16, float* dgamma, float* dbeta,
+                                float alpha, float beta_acc, int64_t rows, int64_t D, void* ws, int64_t ws_bytes,
+                                hipStream_t stream) {
+  VJ_CHECK_ARG(D % 8 == 0 && D <= 512 * LN_MAX_CHUNKS, "vj_layernorm_bwd: D=%ld unsupported", (long)D);
+  VJ_CHECK_ARG(ws_bytes >= vj_layernorm_bwd_ws_bytes(D), "vj_layernorm_bwd: workspace too small");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), 0, stream, (const bf16_t*)dy_bf16,
+                     (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws,
+                     rows, (int)D);
+  VJ_LAUNCH_CHECK("vj_layernorm_bwd");
+  // partial layout [blk][2][D] -> view as P=LN_BWD_BLOCKS rows of 2D columns; reduce halves separately
+  int rc = vj_reduce_partials_strided((const float*)ws, dgamma, LN_BWD_BLOCKS, D, 2 * D, alpha, beta_acc, stream);
+  if (rc) return rc;
+  return vj_reduce_partials_strided((const float*)ws + D, dbeta, LN_BWD_BLOCKS, D, 2 * D, alpha, beta_acc, stream);
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* __restrict__ part,
+                                                                      float* __restrict__ out, int64_t P, int64_t N,
+                                                                      int64_t stride, float alpha, float beta) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int64_t p = 0; p < P; p++) s += part[p * stride + n];
+  s *= alpha;
+  if (beta != 0.f) s += beta * out[n];
+  out[n] = s;
+}
+
+int vj_reduce_partials_strided(const float* part, float* out, int64_t P, int64_t N, int64_t stride, float alpha,
+                               float beta, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, stream, part, out,
+                     P, N, stride, alpha, beta);
+  VJ_LAUNCH_CHECK("vj_reduce_partials_strided");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// target_rows: h[b,k,:] = LN_noaffine_{eps2}( LN_{gamma,beta,eps1}( x[b, idx[b,k], :] ) )   fp32 out
+// (final encoder norm + F.layer_norm + apply_masks fused; only the K predicted rows are ever normalised)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void target_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const int64_t* __restrict__ idx, float* __restrict__ h,
+                                                          int64_t B, int64_t N, int64_t K, int D, float eps1,
+                                                          float eps2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const float invD = 1.0f / (float)D;
+  for (int64_t r = wave; r < B * K; r += nw) {
+    const int64_t b = r / K;
+    const bf16_t* xp = x + (b * N + idx[r]) * D;
+    float v[LN_MAX_CHUNKS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+        load8(xp + c, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[i][j];
+      }
+    }
+    float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float d = v[i][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+    float rstd = rsqrtf(wave_sum(q) * invD + eps1);
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          v[i][j] = (v[i][j] - mean) * rstd * gamma[c + j] + beta[c + j];
+          s += v[i][j];
+        }
+      }
+    }
+    mean = wave_sum(s) * invD;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float d = v[i][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+    rstd = rsqrtf(wave_sum(q) * invD + eps2);
+    float* hp = h + r * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+        float4 o0, o1;
+        o0.x = (v[i][0] - mean) * rstd;
+        o0.y = (v[i][1] - mean) * rstd;
+        o0.z = (v[i][2] - mean) * rstd;
+        o0.w = (v[i][3] - mean) * rstd;
+        o1.x = (v[i][4] - mean) * rstd;
+        o1.y = (v[i][5] - mean) * rstd;
+        o1.z = (v[i][6] - mean) * rstd;
+        o1.w = (v[i][7] - mean) * rstd;
+        *(float4*)(hp + c) = o0;
+        *(float4*)(hp + c + 4) = o1;
+      }
+    }
+  }
+}
+
+extern "C" int vj_target_rows(const void* x_bf16, const float* gamma, const float* beta, const int64_t* idx,
+                              float* h, int64_t B, int64_t N, int64_t K, int64_t D, float eps_norm, float eps_ln,
+                              hipStream_t stream) {
+  VJ_CHECK_ARG(D % 8 == 0 && D <= 512 * LN_MAX_CHUNKS, "vj_target_rows: D=%ld unsupported", (long)D);
+  if (B * K == 0) return 0;
+  hipLaunchKernelGGL(target_rows_kernel, dim3(ln_grid(B * K)), dim3(256), 0, stream, (const bf16_t*)x_bf16, gamma,
+                     beta, idx, h, B, N, K, (int)D, eps_norm, eps_ln);
+  VJ_LAUNCH_CHECK("vj_target_rows");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// latent_loss: sum |z-h|^p / p over all elements (z bf16, h fp32), deterministic two-stage reduction,
+// optionally writing dz = sign(z-h)*|z-h|^(p-1) * gscale (bf16) in the same pass.
+// part[blk] holds the block sums; finish kernel folds them:  out[slot] = scale * sum.
+// ---------------------------------------------------------------------------------------------
+#define LOSS_BLOCKS 512
+__global__ __launch_bounds__(256) void latent_loss_kernel(const bf16_t* __restrict__ z, const float* __restrict__ h,
+                                                          bf16_t* __restrict__ dz, float* __restrict__ part,
+                                                          int64_t n8, float p, float gscale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n8; q += (int64_t)gridDim.x * 256) {
+    float zv[8];
+    load8(z + q * 8, zv);
+    const float4 h0 = *(const float4*)(h + q * 8);
+    const float4 h1 = *(const float4*)(h + q * 8 + 4);
+    const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float d = zv[j] - hv[j];
+      const float a = fabsf(d);
+      if (p == 1.0f) {
+        acc += a;
+        g[j] = (d > 0.f) ? gscale : ((d < 0.f) ? -gscale : 0.f);
+      } else {
+        acc += __powf(a, p) / p;
+        const float m = (a > 0.f) ? __powf(a, p - 1.0f) : 0.f;
+        g[j] = (d > 0.f) ? m * gscale : -m * gscale;
+      }
+    }
+    if (dz) store8(dz + q * 8, g);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void scalar_finish_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out,
+                                     int accumulate) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (red[0] + red[1] + red[2] + red[3]) * scale;
+    *out = accumulate ? (*out + v) : v;
+  }
+}
+
+extern "C" int64_t vj_latent_loss_ws_bytes(void) { return LOSS_BLOCKS * 4; }
+
+// loss_out (device scalar) = [accumulate ? loss_out : 0] + out_scale * sum(|z-h|^p / p)
+extern "C" int vj_latent_loss(const void* z_bf16, const float* h, void* dz_bf16, int64_t numel, float p,
+                              float gscale, float out_scale, int accumulate, float* loss_out, void* ws,
+                              int64_t ws_bytes, hipStream_t stream) {
+  VJ_CHECK_ARG(numel % 8 == 0, "vj_latent_loss: numel=%ld must be a multiple of 8", (long)numel);
+  VJ_CHECK_ARG(ws_bytes >= vj_latent_loss_ws_bytes(), "vj_latent_loss: workspace too small");
+  VJ_CHECK_ARG(p > 0.f, "vj_latent_loss: loss_exp must be > 0");
+  if (numel == 0) return 0;
+  hipLaunchKernelGGL(latent_loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, stream, (const bf16_t*)z_bf16, h,
+                     (bf16_t*)dz_bf16, (float*)ws, numel / 8, p, gscale);
+  VJ_LAUNCH_CHECK("vj_latent_loss");
+  hipLaunchKernelGGL(scalar_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, LOSS_BLOCKS, out_scale,
+                     loss_out, accumulate);
+  VJ_LAUNCH_CHECK("vj_latent_loss(finish)");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// token_pstd: pstd[b,d] (+)= sqrt(unbiased_var_k z[b,k,d] + 1e-4)   (reg_fn, train.py:448-449)
+// one block per (b, 256-column slab); two-pass over the K rows for accuracy.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void token_pstd_kernel(const bf16_t* __restrict__ z, float* __restrict__ pstd,
+                                                         int64_t K, int D, int accumulate) {
+  const int64_t b = blockIdx.y;
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  const bf16_t* zp = z + b * K * D + d;
+  float s = 0.f;
+  for (int64_t k = 0; k < K; k++) s += bf2f(zp[k * D]);
+  const float mean = s / (float)K;
+  float q = 0.f;
+  for (int64_t k = 0; k < K; k++) {
+    const float t = bf2f(zp[k * D]) - mean;
+    q += t * t;
+  }
+  const float v = sqrtf(q / (float)(K - 1) + 1e-4f);
+  float* o = pstd + b * D + d;
+  *o = accumulate ? (*o + v) : v;
+}
+
+// reg = mean(relu(1 - pstd_sum / n_masks))
+__global__ __launch_bounds__(256) void reg_finish_kernel(const float* __restrict__ pstd, int64_t n, float inv_masks,
+                                                         float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += fmaxf(0.f, 1.0f - pstd[i] * inv_masks);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+
+extern "C" int vj_token_pstd(const void* z_bf16, float* pstd, int64_t B, int64_t K, int64_t D, int accumulate,
+                             hipStream_t stream) {
+  VJ_CHECK_ARG(K >= 2, "vj_token_pstd: need at least 2 tokens for an unbiased variance (K=%ld)", (long)K);
+  if (B * D == 0) return 0;
+  hipLaunchKernelGGL(token_pstd_kernel, dim3((unsigned)cdiv64(D, 256), (unsigned)B), dim3(256), 0, stream,
+                     (const bf16_t*)z_bf16, pstd, K, (int)D, accumulate);
+  VJ_LAUNCH_CHECK("vj_token_pstd");
+  return 0;
+}
+
+extern "C" int vj_reg_finish(const float* pstd_sum, int64_t n, int64_t n_masks, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(256), 0, stream, pstd_sum, n, 1.0f / (float)n_masks, out);
+  VJ_LAUNCH_CHECK("vj_reg_finish");
+  return 0;
+}

@@ -1,0 +1,92 @@
+"""ctypes binding of libvjepa_hip.so (include/vjepa_hip.h).
+
+The library is the product: there is NO fallback.  `load_library()` raises if the shared object is missing or a
+declared symbol is absent; every wrapper raises HipKernelError on a non-zero return code.
+torch must be imported first so the HIP runtime the kernels bind to is the one torch already loaded
+(both carry SONAME libamdhip64.so.7).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch/lib/libamdhip64.so before our DT_NEEDED is resolved)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvjepa_hip.so")
+
+P = ctypes.c_void_p
+I64 = ctypes.c_int64
+I32 = ctypes.c_int
+F32 = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/vjepa_hip.h one to one
+SIGNATURES = {
+    "vj_abi_version": (I32, []),
+    "vj_last_error": (ctypes.c_char_p, []),
+    "vj_gather_rows": (I32, [P, P, P, I64, I64, I64, I64, P]),
+    "vj_scatter_rows": (I32, [P, P, P, I64, I64, I64, I64, P]),
+    "vj_copy_rows": (I32, [P, P, I64, I64, I64, I64, I64, I64, I64, P]),
+    "vj_tubelet_pack": (I32, [P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, P]),
+    "vj_add_pos": (I32, [P, P, P, I64, I64, I64, P]),
+    "vj_layernorm_fwd": (I32, [P, P, P, P, P, P, I64, I64, F32, P]),
+    "vj_layernorm_bwd_ws_bytes": (I64, [I64]),
+    "vj_layernorm_bwd": (I32, [P, P, P, P, P, P, P, P, P, F32, F32, I64, I64, P, I64, P]),
+    "vj_gemm_bf16_nt": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, P, P, I64, I32, F32, F32, I32, P]),
+    "vj_transpose_bf16": (I32, [P, P, I64, I64, I64, I64, P]),
+    "vj_colsum_ws_bytes": (I64, [I64]),
+    "vj_colsum_bf16": (I32, [P, I64, I64, I64, I64, I64, I64, P, F32, F32, P, I64, P]),
+    "vj_reduce_partials": (I32, [P, P, I64, I64, F32, F32, P]),
+    "vj_attn_fwd": (I32, [P, P, P, I64, I64, I64, I64, F32, P]),
+    "vj_attn_bwd_ws_bytes": (I64, [I64, I64, I64]),
+    "vj_attn_bwd": (I32, [P, P, P, P, P, I64, I64, I64, I64, F32, P, I64, P]),
+    "vj_pred_assemble_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, P]),
+    "vj_target_rows": (I32, [P, P, P, P, P, I64, I64, I64, I64, F32, F32, P]),
+    "vj_latent_loss_ws_bytes": (I64, []),
+    "vj_latent_loss": (I32, [P, P, P, I64, F32, F32, F32, I32, P, P, I64, P]),
+    "vj_token_pstd": (I32, [P, P, I64, I64, I64, I32, P]),
+    "vj_reg_finish": (I32, [P, I64, I64, P, P]),
+    "vj_adamw_ema": (I32, [P, P, P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, F32, P]),
+    "vj_ema_update": (I32, [P, P, P, I64, F32, P]),
+    "vj_cast_f32_to_bf16": (I32, [P, P, I64, P]),
+    "vj_sqnorm_ws_bytes": (I64, []),
+    "vj_sqnorm_f32": (I32, [P, I64, P, I32, P, I64, P]),
+    "vj_probe_tr16": (I32, [P, I32, P]),
+    "vj_probe_copy": (I32, [P, P, I64, P]),
+}
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libvjepa_hip.so and bind every symbol of the C ABI.  Fails loudly -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipKernelError(
+            f"{_LIB_PATH} is missing: build it with `python -m jepa_amd.build` (hipcc, gfx950). "
+            "jepa_amd has no fallback compute path.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipKernelError(f"libvjepa_hip.so does not export {name}; rebuild the library") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load_library().vj_last_error()
+        raise HipKernelError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

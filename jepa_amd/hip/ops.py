@@ -1,0 +1,291 @@
+"""Tensor-level wrappers over the C ABI (include/vjepa_hip.h).
+
+Every function takes CUDA(HIP) torch tensors, validates dtype/contiguity, and enqueues the kernel on
+`torch.cuda.current_stream()` (or the `stream=` handle given).  PyTorch is only the allocator and stream
+provider here; no torch operator computes anything on this path.
+"""
+import ctypes
+
+import torch
+
+from .lib import check, load_library
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+I64 = torch.int64
+
+EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32 = 0, 1, 2, 3
+
+
+def _stream(stream=None):
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: must live on the GPU (jepa_amd has no CPU compute path)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+class Scratch:
+    """Per-device scratch workspace reused by kernels that need partial-sum buffers."""
+
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes, device, tag="default"):
+        key = (str(device), tag)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+
+# ---------------------------------------------------------------- rows
+def gather_rows(src, idx, out=None, stream=None):
+    """out[b,k,:] = src[b, idx[b,k], :]; src [B,N,D] or a broadcast table [1,N,D] / [N,D].  Bit-exact."""
+    lib = load_library()
+    idx = _req(idx, I64, "idx")
+    B, K = idx.shape
+    if not src.is_contiguous():
+        raise ValueError("src must be contiguous")
+    D = src.shape[-1]
+    if src.dim() == 2 or (src.shape[0] == 1 and B > 1):
+        bstride = 0  # broadcast table (pos-embed)
+    elif src.dim() == 3 and src.shape[0] == B:
+        bstride = src.shape[1]
+    else:
+        raise ValueError(f"gather_rows: batch mismatch src {tuple(src.shape)} idx {tuple(idx.shape)}")
+    if out is None:
+        out = torch.empty((B, K, D), dtype=src.dtype, device=src.device)
+    check(lib.vj_gather_rows(_ptr(src), _ptr(out), _ptr(idx), B, K, D * src.element_size(), bstride, _stream(stream)),
+          "vj_gather_rows")
+    return out
+
+
+def scatter_rows(src, idx, N, stream=None):
+    """zeros[B,N,D] with out[b, idx[b,k], :] = src[b,k,:] (backward of gather_rows)."""
+    lib = load_library()
+    idx = _req(idx, I64, "idx")
+    B, K = idx.shape
+    D = src.shape[-1]
+    out = torch.empty((B, N, D), dtype=src.dtype, device=src.device)
+    check(lib.vj_scatter_rows(_ptr(src.contiguous()), _ptr(out), _ptr(idx), B, N, K, D * src.element_size(),
+                              _stream(stream)), "vj_scatter_rows")
+    return out
+
+
+def copy_rows(src, dst, B, src_rows, src_off, dst_rows, dst_off, n, D, stream=None):
+    lib = load_library()
+    check(lib.vj_copy_rows(_ptr(src), _ptr(dst), B, src_rows, src_off, dst_rows, dst_off, n, D, _stream(stream)),
+          "vj_copy_rows")
+    return dst
+
+
+def tubelet_pack(clips, tubelet, patch, idx=None, out=None, stream=None):
+    lib = load_library()
+    clips = _req(clips, F32, "clips")
+    B, C, T, H, W = clips.shape
+    N = (T // tubelet) * (H // patch) * (W // patch)
+    K = N if idx is None else idx.shape[1]
+    kdim = C * tubelet * patch * patch
+    if out is None:
+        out = torch.empty((B * K, kdim), dtype=BF16, device=clips.device)
+    check(lib.vj_tubelet_pack(_ptr(clips), _ptr(out), _ptr(idx), B, C, T, H, W, tubelet, patch, K, _stream(stream)),
+          "vj_tubelet_pack")
+    return out
+
+
+def add_pos(x, pos, B, K, idx=None, stream=None):
+    """x [B*K, D] bf16 += pos[(idx or arange)[b,k]] (fp32 table [N,D])."""
+    lib = load_library()
+    _req(x, BF16, "x")
+    _req(pos, F32, "pos")
+    check(lib.vj_add_pos(_ptr(x), _ptr(pos), _ptr(idx), B, K, x.shape[-1], _stream(stream)), "vj_add_pos")
+    return x
+
+
+# ---------------------------------------------------------------- layernorm
+def layernorm_fwd(x, gamma, beta, eps, save_stats=True, out=None, stream=None):
+    lib = load_library()
+    _req(x, BF16, "x")
+    rows, D = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x) if out is None else out
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=F32, device=x.device)
+        rstd = torch.empty(rows, dtype=F32, device=x.device)
+    check(lib.vj_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, D, eps,
+                               _stream(stream)), "vj_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, alpha=1.0, accumulate=False, stream=None):
+    lib = load_library()
+    _req(dy, BF16, "dy")
+    rows, D = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x)
+    nws = lib.vj_layernorm_bwd_ws_bytes(D)
+    ws = Scratch.get(nws, x.device, "ln")
+    check(lib.vj_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
+                               _ptr(dgamma), _ptr(dbeta), alpha, 1.0 if accumulate else 0.0, rows, D, _ptr(ws), nws,
+                               _stream(stream)), "vj_layernorm_bwd")
+    return dx
+
+
+# ---------------------------------------------------------------- gemm
+GEMM_FLAGS = 0  # bit0: register-staged operands instead of LDS-DMA (set by tests for A/B runs)
+
+
+def gemm_nt(A, B, out=None, bias=None, residual=None, aux_in=None, aux_out=None, epilogue=EPI_BF16, alpha=1.0,
+            beta=0.0, M=None, K=None, flags=None, stream=None):
+    """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  A,B bf16 2-D (row stride may exceed K)."""
+    lib = load_library()
+    _req(A, BF16, "A")
+    _req(B, BF16, "B")
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = B.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if epilogue == EPI_F32 else BF16, device=A.device)
+    aux = aux_in if aux_in is not None else aux_out
+    check(lib.vj_gemm_bf16_nt(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), M, N, K,
+                              _ptr(bias), _ptr(residual), 0 if residual is None else residual.stride(0),
+                              _ptr(aux_in), _ptr(aux_out), 0 if aux is None else aux.stride(0), epilogue, alpha, beta,
+                              GEMM_FLAGS if flags is None else flags, _stream(stream)), "vj_gemm_bf16_nt")
+    return out
+
+
+def pad64(m):
+    return (m + 63) // 64 * 64
+
+
+def transpose(x, M=None, out=None, stream=None):
+    """x [M,N] bf16 -> [N, pad64(M)] (zero padded): K-contiguous wgrad operand."""
+    lib = load_library()
+    _req(x, BF16, "x")
+    M = x.shape[0] if M is None else M
+    N = x.shape[1]
+    Mp = pad64(M)
+    if out is None:
+        out = torch.empty((N, Mp), dtype=BF16, device=x.device)
+    check(lib.vj_transpose_bf16(_ptr(x), _ptr(out), M, N, x.stride(0), Mp, _stream(stream)), "vj_transpose_bf16")
+    return out
+
+
+def colsum(x, out, M=None, alpha=1.0, accumulate=False, group=0, row_lo=0, row_hi=None, stream=None):
+    """out[n] (fp32) = alpha * sum_m x[m,n] (+ out); optional per-sample row window for the mask-token grad."""
+    lib = load_library()
+    _req(x, BF16, "x")
+    M = x.shape[0] if M is None else M
+    N = x.shape[1]
+    nws = lib.vj_colsum_ws_bytes(N)
+    ws = Scratch.get(nws, x.device, "colsum")
+    if group <= 0:
+        group, row_lo, row_hi = max(M, 1), 0, max(M, 1)
+    check(lib.vj_colsum_bf16(_ptr(x), M, N, x.stride(0), group, row_lo, row_hi, _ptr(out), alpha,
+                             1.0 if accumulate else 0.0, _ptr(ws), nws, _stream(stream)), "vj_colsum_bf16")
+    return out
+
+
+# ---------------------------------------------------------------- attention
+def attn_fwd(qkv, B, S, H, hd, scale, save_lse=True, out=None, stream=None):
+    """qkv [B*S, 3*H*hd] bf16 (packed [B,S,3,H,hd]) -> o [B*S, H*hd], lse2 [B,H,S]."""
+    lib = load_library()
+    _req(qkv, BF16, "qkv")
+    o = torch.empty((B * S, H * hd), dtype=BF16, device=qkv.device) if out is None else out
+    lse = torch.empty((B, H, S), dtype=F32, device=qkv.device) if save_lse else None
+    check(lib.vj_attn_fwd(_ptr(qkv), _ptr(o), _ptr(lse), B, S, H, hd, scale, _stream(stream)), "vj_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
+    lib = load_library()
+    _req(dout, BF16, "dout")
+    dqkv = torch.empty_like(qkv) if out is None else out
+    nws = lib.vj_attn_bwd_ws_bytes(B, S, H)
+    ws = Scratch.get(nws, qkv.device, "attn")
+    check(lib.vj_attn_bwd(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), B, S, H, hd, scale, _ptr(ws), nws,
+                          _stream(stream)), "vj_attn_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------- predictor / loss
+def pred_assemble(e, mask_token, pos, idx_e, idx_p, stream=None):
+    lib = load_library()
+    _req(e, BF16, "e")
+    B, Ke = idx_e.shape
+    Kp = idx_p.shape[1]
+    D = e.shape[-1]
+    out = torch.empty((B * (Ke + Kp), D), dtype=BF16, device=e.device)
+    check(lib.vj_pred_assemble_fwd(_ptr(e), _ptr(mask_token), _ptr(pos), _ptr(idx_e), _ptr(idx_p), _ptr(out), B, Ke,
+                                   Kp, D, _stream(stream)), "vj_pred_assemble_fwd")
+    return out
+
+
+def target_rows(x, gamma, beta, idx, B, N, eps_norm, eps_ln=1e-5, stream=None):
+    lib = load_library()
+    _req(x, BF16, "x")
+    K = idx.shape[1]
+    D = x.shape[-1]
+    h = torch.empty((B, K, D), dtype=F32, device=x.device)
+    check(lib.vj_target_rows(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(idx), _ptr(h), B, N, K, D, eps_norm, eps_ln,
+                             _stream(stream)), "vj_target_rows")
+    return h
+
+
+def latent_loss(z, h, loss_out, p=1.0, out_scale=1.0, accumulate=False, dz=None, gscale=0.0, stream=None):
+    lib = load_library()
+    _req(z, BF16, "z")
+    _req(h, F32, "h")
+    nws = lib.vj_latent_loss_ws_bytes()
+    ws = Scratch.get(nws, z.device, "loss")
+    check(lib.vj_latent_loss(_ptr(z), _ptr(h), _ptr(dz), z.numel(), p, gscale, out_scale, int(accumulate),
+                             _ptr(loss_out), _ptr(ws), nws, _stream(stream)), "vj_latent_loss")
+    return loss_out
+
+
+def token_pstd(z, pstd, B, K, D, accumulate, stream=None):
+    lib = load_library()
+    check(lib.vj_token_pstd(_ptr(z), _ptr(pstd), B, K, D, int(accumulate), _stream(stream)), "vj_token_pstd")
+
+
+def reg_finish(pstd, n_masks, out, stream=None):
+    lib = load_library()
+    check(lib.vj_reg_finish(_ptr(pstd), pstd.numel(), n_masks, _ptr(out), _stream(stream)), "vj_reg_finish")
+
+
+# ---------------------------------------------------------------- optimizer
+def adamw_ema(p, g, m, v, p_bf16, tgt, tgt_bf16, lr, wd, beta1, beta2, eps, step, gscale, ema, stream=None):
+    lib = load_library()
+    check(lib.vj_adamw_ema(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), _ptr(tgt), _ptr(tgt_bf16), p.numel(),
+                           lr, wd, beta1, beta2, eps, step, gscale, ema, _stream(stream)), "vj_adamw_ema")
+
+
+def ema_update(tgt, src, tgt_bf16, m, stream=None):
+    lib = load_library()
+    check(lib.vj_ema_update(_ptr(tgt), _ptr(src), _ptr(tgt_bf16), tgt.numel(), m, _stream(stream)), "vj_ema_update")
+
+
+def cast_bf16(src, dst, stream=None):
+    lib = load_library()
+    check(lib.vj_cast_f32_to_bf16(_ptr(src), _ptr(dst), src.numel(), _stream(stream)), "vj_cast_f32_to_bf16")
+    return dst
+
+
+def sqnorm(g, out2, accumulate=False, stream=None):
+    lib = load_library()
+    nws = lib.vj_sqnorm_ws_bytes()
+    ws = Scratch.get(nws, g.device, "sqnorm")
+    check(lib.vj_sqnorm_f32(_ptr(g), g.numel(), _ptr(out2), int(accumulate), _ptr(ws), nws, _stream(stream)),
+          "vj_sqnorm_f32")
+    return out2

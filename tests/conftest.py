@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (only present in the build container)")
+
+
+def pytest_collection_modifyitems(config, items):
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    has_ref = os.path.isdir("/root/reference/src")
+    for item in items:
+        if "gpu" in item.keywords and not has_gpu:
+            item.add_marker(pytest.mark.skip(reason="no GPU on this host"))
+        if "reference" in item.keywords and not has_ref:
+            item.add_marker(pytest.mark.skip(reason="/root/reference not present"))
