@@ -1,0 +1,105 @@
+"""Data-parallel gradient averaging for the V-JEPA step: bucketed all-reduce over RCCL (xGMI) on a side HIP
+stream, overlapped with the hand-written backward.
+
+The reference wraps encoder/predictor in DistributedDataParallel (app/vjepa/train.py:295-297), whose reducer
+only sees encoder gradients become final during the LAST of four backward passes (MultiMaskWrapper re-enters the
+backbone per mask).  Here both masks share one chain, so a transformer layer's weight gradients are final as
+soon as that layer's backward has been enqueued: `layer_done` records an event on the compute stream and
+launches the all-reduce of that layer's contiguous slice of the gradient arena on the communication stream.
+Small tensors (biases, LayerNorm affine, mask tokens) are reduced in one tail bucket.  The SUM is turned into the
+mean inside the fused AdamW kernel (gscale = 1/world), so no extra pass touches the gradients.
+
+With world_size == 1 every method is a no-op.  On CPU tensors (gloo, used by the tests) the same bucket walk
+runs synchronously.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, arena, vit, pred, world_size, overlap=True, pred_layers_per_bucket=4):
+        self.arena = arena
+        self.world = world_size
+        self.enabled = world_size > 1
+        self.overlap = overlap
+        self.buckets = {}      # (kind, layer) -> list of (lo, hi) ranges of arena.G that become final at that hook
+        self.tail = []
+        self._pending = []
+        self.comm_stream = None
+        self.launched = []     # (lo, hi) in launch order -- inspected by tests
+        if not self.enabled:
+            return
+        sl = arena.slots
+
+        def span(prefix, names):
+            offs = [sl[prefix + n] for n in names]
+            return (min(s.off for s in offs), max(s.off + ((s.numel + 63) // 64) * 64 for s in offs))
+
+        mats = ["attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"]
+        for li in range(len(vit.blocks)):
+            self.buckets[("enc", li)] = [span(f"enc.blocks.{li}.", mats)]
+        self.buckets[("enc", -1)] = [span("enc.", ["patch_embed.proj.weight"])]
+        n_pred = len(pred.predictor_blocks)
+        group = []
+        for li in range(n_pred - 1, -1, -1):
+            group.append(span(f"pred.predictor_blocks.{li}.", mats))
+            if len(group) == pred_layers_per_bucket or li == 0:
+                self.buckets[("pred", li)] = [(min(g[0] for g in group), max(g[1] for g in group))]
+                group = []
+        self.buckets[("pred", n_pred)] = [span("pred.", ["predictor_proj.weight"])]
+        # everything not covered above (small tensors + predictor_embed + mask tokens) goes in the tail
+        covered = sorted(r for rs in self.buckets.values() for r in rs)
+        pos, total = 0, arena.total
+        for lo, hi in covered:
+            if lo > pos:
+                self.tail.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < total:
+            self.tail.append((pos, total))
+
+    def begin(self):
+        if not self.enabled:
+            return
+        self.launched = []
+        self._pending = []
+        if self.arena.G.is_cuda and self.overlap and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.arena.G.device)
+
+    def _reduce(self, lo, hi):
+        g = self.arena.G[lo:hi]
+        self.launched.append((lo, hi))
+        if g.is_cuda and self.overlap:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+
+    def layer_done(self, kind, layer):
+        if not self.enabled:
+            return
+        for lo, hi in self.buckets.get((kind, layer), ()):
+            self._reduce(lo, hi)
+
+    def finish(self):
+        """Reduce the tail bucket and make the compute stream wait for every outstanding bucket."""
+        if not self.enabled:
+            return
+        for lo, hi in self.tail:
+            self._reduce(lo, hi)
+        if self.arena.G.is_cuda and self.overlap:
+            for w in self._pending:
+                w.wait()   # enqueues a wait of the current (compute) stream on the collective; no host block
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._pending = []
+
+
+def broadcast_parameters(arena, tarena=None, src=0):
+    """One-time parameter sync from rank 0 (DDP's _sync_module_states, reference train.py:295-297)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    dist.broadcast(arena.P, src)
+    if tarena is not None:
+        dist.broadcast(tarena.P, src)

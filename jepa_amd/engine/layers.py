@@ -1,0 +1,211 @@
+"""Hand-written forward / backward chains of the V-JEPA encoder and predictor over the C-ABI kernels.
+
+No autograd graph: every chain saves exactly the activations its backward needs and the backward walks the layers
+in reverse, writing weight gradients (fp32) straight into the gradient-arena views.  Both masks of a step run
+through ONE chain: their token rows are concatenated along M (bigger GEMMs, each weight gradient produced in one
+piece -- which is also what makes a layer's gradient bucket final as soon as that layer's backward is done), and
+only attention, which is per-sequence, is launched per mask segment.
+
+Reference semantics restated (never copied):
+  Block / Attention / MLP        src/models/utils/modules.py:13-120
+  VisionTransformer.forward      src/models/vision_transformer.py:159-195
+  VisionTransformerPredictor     src/models/predictor.py:174-239
+  MultiMask wrappers             src/models/utils/multimask.py:11-48
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from ..hip import ops
+from .weights import BlockW, EncoderW, LinearW, PredictorW
+
+LN_EPS = 1e-6  # partial(nn.LayerNorm, eps=1e-6), vision_transformer.py:252-281 / predictor.py:242-246
+
+
+@dataclass
+class Seg:
+    """A group of B equal-length sequences occupying rows [row0, row0 + B*S) of the token matrix."""
+    row0: int
+    B: int
+    S: int
+
+    @property
+    def rows(self):
+        return self.B * self.S
+
+
+def _rows(t, seg):
+    return t[seg.row0:seg.row0 + seg.rows]
+
+
+# =============================================================================================== block
+def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
+    """x [M, D] bf16 -> x2 [M, D]; returns (x2, saved)."""
+    D = x.shape[1]
+    hd = D // heads
+    scale = hd ** -0.5
+    y1, mean1, rstd1 = ops.layernorm_fwd(x, bw.norm1.g, bw.norm1.b, LN_EPS, save_stats=save)
+    qkv = ops.gemm_nt(y1, bw.qkv.w, bias=bw.qkv.b)
+    o = torch.empty_like(x)
+    lses = []
+    for sg in segs:
+        _, lse = ops.attn_fwd(_rows(qkv, sg), sg.B, sg.S, heads, hd, scale, save_lse=save, out=_rows(o, sg))
+        lses.append(lse)
+    x1 = ops.gemm_nt(o, bw.proj.w, bias=bw.proj.b, residual=x)
+    y2, mean2, rstd2 = ops.layernorm_fwd(x1, bw.norm2.g, bw.norm2.b, LN_EPS, save_stats=save)
+    u = torch.empty((x.shape[0], bw.fc1.w.shape[0]), dtype=torch.bfloat16, device=x.device) if save else None
+    g = ops.gemm_nt(y2, bw.fc1.w, bias=bw.fc1.b, aux_out=u, epilogue=ops.EPI_GELU)
+    x2 = ops.gemm_nt(g, bw.fc2.w, bias=bw.fc2.b, residual=x1)
+    saved = (x, y1, mean1, rstd1, qkv, o, lses, x1, y2, mean2, rstd2, u, g) if save else None
+    return x2, saved
+
+
+def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None):
+    """dW (fp32, into lw.gw) = alpha * dy^T x_in ; db = alpha * colsum(dy) ; returns dx = dy W (bf16)."""
+    dyT = ops.transpose(dy)
+    xT = ops.transpose(x_in)
+    ops.gemm_nt(dyT, xT, out=lw.gw, epilogue=ops.EPI_F32, alpha=alpha, M=lw.gw.shape[0], K=dyT.shape[1])
+    if lw.gb is not None:
+        ops.colsum(dy, lw.gb, alpha=alpha)
+    if not need_dx:
+        return None
+    if dgelu_aux is not None:
+        return ops.gemm_nt(dy, lw.wT, aux_in=dgelu_aux, epilogue=ops.EPI_DGELU)
+    return ops.gemm_nt(dy, lw.wT)
+
+
+def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: float):
+    x, y1, mean1, rstd1, qkv, o, lses, x1, y2, mean2, rstd2, u, g = saved
+    D = x.shape[1]
+    hd = D // heads
+    scale = hd ** -0.5
+    du = _linear_backward(dx2, g, bw.fc2, alpha, dgelu_aux=u)           # fc2 dgrad fused with GELU'
+    dy2 = _linear_backward(du, y2, bw.fc1, alpha)
+    dx1 = ops.layernorm_bwd(dy2, x1, bw.norm2.g, mean2, rstd2, bw.norm2.gg, bw.norm2.gb, dres=dx2, alpha=alpha)
+    do = _linear_backward(dx1, o, bw.proj, alpha)
+    dqkv = torch.empty_like(qkv)
+    for sg, lse in zip(segs, lses):
+        ops.attn_bwd(_rows(qkv, sg), _rows(o, sg), _rows(do, sg), lse, sg.B, sg.S, heads, hd, scale,
+                     out=_rows(dqkv, sg))
+    dy1 = _linear_backward(dqkv, y1, bw.qkv, alpha)
+    return ops.layernorm_bwd(dy1, x, bw.norm1.g, mean1, rstd1, bw.norm1.gg, bw.norm1.gb, dres=dx1, alpha=alpha)
+
+
+# =============================================================================================== encoder
+def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], save: bool, final_norm=True):
+    """clips fp32 [B,3,T,H,W]; masks: None (all N tokens) or a list of int64 [B,K_i] index tensors.
+    Returns (out [sum_i B*K_i, D] bf16, segs, saved).  With final_norm=False the last residual stream is returned
+    (the target path fuses the final norm into vj_target_rows)."""
+    B = clips.shape[0]
+    D = ew.patch.w.shape[0]
+    kdim = ew.patch.w.shape[1]
+    N = ew.pos.shape[0]
+    if masks is None:
+        segs = [Seg(0, B, N)]
+        tok = ops.tubelet_pack(clips, ew.tubelet, ew.patch_size)
+    else:
+        segs, r = [], 0
+        for m in masks:
+            segs.append(Seg(r, B, m.shape[1]))
+            r += B * m.shape[1]
+        tok = torch.empty((r, kdim), dtype=torch.bfloat16, device=clips.device)
+        for sg, m in zip(segs, masks):
+            ops.tubelet_pack(clips, ew.tubelet, ew.patch_size, idx=m, out=_rows(tok, sg))
+    x = ops.gemm_nt(tok, ew.patch.w, bias=ew.patch.b)
+    for i, sg in enumerate(segs):
+        ops.add_pos(_rows(x, sg), ew.pos, sg.B, sg.S, idx=None if masks is None else masks[i])
+    saved_blocks = []
+    for bw in ew.blocks:
+        x, sv = block_forward(x, bw, segs, ew.heads, save)
+        saved_blocks.append(sv)
+    if not final_norm:
+        return x, segs, None
+    out, mean, rstd = ops.layernorm_fwd(x, ew.norm.g, ew.norm.b, LN_EPS, save_stats=save)
+    saved = (tok, saved_blocks, x, mean, rstd) if save else None
+    return out, segs, saved
+
+
+def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_done=None):
+    """dout [M, D] bf16: gradient of the encoder output rows.  Pixels need no gradient."""
+    tok, saved_blocks, xl, mean, rstd = saved
+    dx = ops.layernorm_bwd(dout, xl, ew.norm.g, mean, rstd, ew.norm.gg, ew.norm.gb, alpha=alpha)
+    for li in range(len(ew.blocks) - 1, -1, -1):
+        dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha)
+        saved_blocks[li] = None
+        if on_layer_done is not None:
+            on_layer_done("enc", li)
+    _linear_backward(dx, tok, ew.patch, alpha, need_dx=False)
+    if on_layer_done is not None:
+        on_layer_done("enc", -1)
+
+
+# =============================================================================================== predictor
+def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_pred, save: bool):
+    """z [sum_i B*Ke_i, D] bf16 (context-encoder output rows, per-mask segments enc_segs).
+    Returns (zhat [sum_i B*Kp_i, D] bf16, tgt_segs, saved)."""
+    Dp = pw.embed.w.shape[0]
+    dev = z.device
+    e = ops.gemm_nt(z, pw.embed.w, bias=pw.embed.b)
+    n_tok = len(pw.mask_tokens)
+    segs, tsegs, r, rt = [], [], 0, 0
+    for sg, mp in zip(enc_segs, masks_pred):
+        Kp = mp.shape[1]
+        segs.append(Seg(r, sg.B, sg.S + Kp))
+        tsegs.append(Seg(rt, sg.B, Kp))
+        r += sg.B * (sg.S + Kp)
+        rt += sg.B * Kp
+    x = torch.empty((r, Dp), dtype=torch.bfloat16, device=dev)
+    for i, (sg, psg) in enumerate(zip(enc_segs, segs)):
+        # mask_index = i % num_mask_tokens (predictor.py:206; PredictorMultiMaskWrapper passes mask_index=i)
+        ops.pred_assemble(_rows(e, sg), pw.mask_tokens[i % n_tok], pw.pos, masks_enc[i], masks_pred[i],
+                          out=_rows(x, psg))
+    saved_blocks = []
+    for bw in pw.blocks:
+        x, sv = block_forward(x, bw, segs, pw.heads, save)
+        saved_blocks.append(sv)
+    # predictor_norm is row-wise and only target rows are projected (x[:, N_ctxt:], predictor.py:233-237):
+    # normalise just those rows.
+    t = torch.empty((rt, Dp), dtype=torch.bfloat16, device=dev)
+    for sg, psg, tsg in zip(enc_segs, segs, tsegs):
+        ops.copy_rows(_rows(x, psg), _rows(t, tsg), psg.B, psg.S, sg.S, tsg.S, 0, tsg.S, Dp)
+    tn, mean, rstd = ops.layernorm_fwd(t, pw.norm.g, pw.norm.b, LN_EPS, save_stats=save)
+    zhat = ops.gemm_nt(tn, pw.proj.w, bias=pw.proj.b)
+    saved = (z, e.shape, segs, tsegs, saved_blocks, t, tn, mean, rstd) if save else None
+    return zhat, tsegs, saved
+
+
+def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_layer_done=None):
+    """dzhat [sum_i B*Kp_i, D] bf16 -> returns dz [sum_i B*Ke_i, D] bf16 (gradient of the encoder output)."""
+    z, e_shape, segs, tsegs, saved_blocks, t, tn, mean, rstd = saved
+    Dp = pw.embed.w.shape[0]
+    n_tok = len(pw.mask_tokens)
+    dtn = _linear_backward(dzhat, tn, pw.proj, alpha)
+    dt = ops.layernorm_bwd(dtn, t, pw.norm.g, mean, rstd, pw.norm.gg, pw.norm.gb, alpha=alpha)
+    total = segs[-1].row0 + segs[-1].rows
+    dx = torch.zeros((total, Dp), dtype=torch.bfloat16, device=dzhat.device)  # context rows start at zero grad
+    for sg, psg, tsg in zip(enc_segs, segs, tsegs):
+        ops.copy_rows(_rows(dt, tsg), _rows(dx, psg), psg.B, tsg.S, 0, psg.S, sg.S, tsg.S, Dp)
+    if on_layer_done is not None:
+        on_layer_done("pred", len(pw.blocks))
+    for li in range(len(pw.blocks) - 1, -1, -1):
+        dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha)
+        saved_blocks[li] = None
+        if on_layer_done is not None:
+            on_layer_done("pred", li)
+    # token assembly backward: mask-token grads = sum of the target rows; context rows flow to predictor_embed
+    de = torch.empty(e_shape, dtype=torch.bfloat16, device=dzhat.device)
+    used = set()
+    for i, (sg, psg) in enumerate(zip(enc_segs, segs)):
+        ti = i % n_tok
+        ops.colsum(_rows(dx, psg), pw.g_mask_tokens[ti], alpha=alpha, accumulate=ti in used, group=psg.S,
+                   row_lo=sg.S, row_hi=psg.S)
+        used.add(ti)
+        ops.copy_rows(_rows(dx, psg), _rows(de, sg), psg.B, psg.S, 0, sg.S, 0, sg.S, Dp)
+    for ti in range(n_tok):
+        if ti not in used:
+            pw.g_mask_tokens[ti].zero_()
+    dz = _linear_backward(de, z, pw.embed, alpha)
+    if on_layer_done is not None:
+        on_layer_done("pred", -1)
+    return dz

@@ -150,8 +150,9 @@ def gemm_nt(A, B, out=None, bias=None, residual=None, aux_in=None, aux_out=None,
             beta=0.0, M=None, K=None, flags=None, stream=None):
     """C[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue.  A,B bf16 2-D (row stride may exceed K)."""
     lib = load_library()
-    _req(A, BF16, "A")
-    _req(B, BF16, "B")
+    for t, nm in ((A, "A"), (B, "B")):
+        if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"gemm_nt: {nm} must be a 2-D bf16 GPU tensor with unit inner stride")
     M = A.shape[0] if M is None else M
     K = A.shape[1] if K is None else K
     N = B.shape[0]
@@ -220,13 +221,14 @@ def attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
 
 
 # ---------------------------------------------------------------- predictor / loss
-def pred_assemble(e, mask_token, pos, idx_e, idx_p, stream=None):
+def pred_assemble(e, mask_token, pos, idx_e, idx_p, out=None, stream=None):
     lib = load_library()
     _req(e, BF16, "e")
     B, Ke = idx_e.shape
     Kp = idx_p.shape[1]
     D = e.shape[-1]
-    out = torch.empty((B * (Ke + Kp), D), dtype=BF16, device=e.device)
+    if out is None:
+        out = torch.empty((B * (Ke + Kp), D), dtype=BF16, device=e.device)
     check(lib.vj_pred_assemble_fwd(_ptr(e), _ptr(mask_token), _ptr(pos), _ptr(idx_e), _ptr(idx_p), _ptr(out), B, Ke,
                                    Kp, D, _stream(stream)), "vj_pred_assemble_fwd")
     return out

@@ -1,0 +1,130 @@
+"""Host-side (CPU) parity of the drop-in Python layer with the reference: position tables, mask collator,
+schedules (against the committed golden fixtures) and -- when /root/reference is mounted -- seed-for-seed model
+initialisation, state-dict names and tensor helpers against the live reference modules."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.golden_util import load_tables  # noqa: E402
+
+VITL_MASKS = [
+    dict(aspect_ratio=(0.75, 1.5), num_blocks=8, spatial_scale=(0.15, 0.15), temporal_scale=(1.0, 1.0),
+         max_temporal_keep=1.0, max_keep=None),
+    dict(aspect_ratio=(0.75, 1.5), num_blocks=2, spatial_scale=(0.7, 0.7), temporal_scale=(1.0, 1.0),
+         max_temporal_keep=1.0, max_keep=None),
+]
+
+
+def test_pos_embed_tables_bit_exact():
+    from jepa_amd.src.models.utils.pos_embs import get_3d_sincos_pos_embed
+    t = load_tables()
+    for D, gs, gd in [(192, 4, 4), (96, 4, 4), (64, 4, 4), (32, 4, 4)]:
+        ours = get_3d_sincos_pos_embed(D, gs, gd, cls_token=False, uniform_power=True)
+        assert np.array_equal(ours.astype(np.float32), t[f"pos3d_{D}_{gs}_{gd}"].astype(np.float32))
+    for D, gs, gd, up in [(1024, 14, 8, True), (384, 14, 8, True), (1280, 24, 8, True), (768, 14, 8, False)]:
+        ours = get_3d_sincos_pos_embed(D, gs, gd, cls_token=False, uniform_power=up)
+        assert np.array_equal(ours[::53].astype(np.float32), t[f"pos3d_rows53_{D}_{gs}_{gd}_{int(up)}"].astype(np.float32))
+
+
+def test_collator_bit_exact_vs_reference_draws():
+    from jepa_amd.src.masks.multiblock3d import MaskCollator
+    t = load_tables()
+    coll = MaskCollator(cfgs_mask=VITL_MASKS, crop_size=224, num_frames=16, patch_size=16, tubelet_size=2)
+    for it in range(3):
+        torch.manual_seed(4321 + it)
+        batch, me, mp = coll([(torch.zeros(1), 0) for _ in range(6)])
+        assert batch[0].shape[0] == 6
+        for i in range(2):
+            assert me[i].dtype == torch.int64 and mp[i].dtype == torch.int64
+            assert np.array_equal(me[i].numpy(), t[f"vitl_it{it}_enc{i}"])
+            assert np.array_equal(mp[i].numpy(), t[f"vitl_it{it}_pred{i}"])
+            # contract: sorted ascending, unique, context and target disjoint
+            assert bool((me[i][:, 1:] > me[i][:, :-1]).all()) and bool((mp[i][:, 1:] > mp[i][:, :-1]).all())
+            for b in range(6):
+                assert not set(me[i][b].tolist()) & set(mp[i][b].tolist())
+    odd = [dict(aspect_ratio=(0.3, 3.0), num_blocks=3, spatial_scale=(0.2, 0.8), temporal_scale=(0.25, 1.0),
+                max_temporal_keep=0.5, max_keep=100)]
+    coll2 = MaskCollator(cfgs_mask=odd, crop_size=224, num_frames=16, patch_size=16, tubelet_size=2)
+    for it in range(3):
+        torch.manual_seed(99 + it)
+        _, me, mp = coll2([(torch.zeros(1), 0) for _ in range(4)])
+        assert np.array_equal(me[0].numpy(), t[f"odd_it{it}_enc0"])
+        assert np.array_equal(mp[0].numpy(), t[f"odd_it{it}_pred0"])
+        assert me[0].shape[1] <= 100
+
+
+def test_collator_step_counter_replay():
+    from jepa_amd.src.masks.multiblock3d import MaskCollator
+    a = MaskCollator(cfgs_mask=VITL_MASKS[:1], crop_size=64, num_frames=8, patch_size=16, tubelet_size=2)
+    b = MaskCollator(cfgs_mask=VITL_MASKS[:1], crop_size=64, num_frames=8, patch_size=16, tubelet_size=2)
+    for _ in range(3):
+        b.step()   # resume path: train.py:322-326 replays the counter
+    torch.manual_seed(0)
+    for _ in range(3):
+        a([(torch.zeros(1), 0)] * 2)
+    torch.manual_seed(7)
+    ra = a([(torch.zeros(1), 0)] * 2)
+    torch.manual_seed(7)
+    rb = b([(torch.zeros(1), 0)] * 2)
+    assert torch.equal(ra[1][0], rb[1][0]) and torch.equal(ra[2][0], rb[2][0])
+
+
+def test_schedules_vs_reference_values():
+    from jepa_amd.src.utils.schedulers import CosineWDSchedule, WarmupCosineSchedule
+    t = load_tables()
+
+    class Opt:
+        param_groups = [{"lr": 0., "weight_decay": 0.}, {"lr": 0., "weight_decay": 0, "WD_exclude": True}]
+    o = Opt()
+    s = WarmupCosineSchedule(o, warmup_steps=12000, start_lr=2e-4, ref_lr=6.25e-4, final_lr=1e-6, T_max=112500)
+    w = CosineWDSchedule(o, ref_wd=0.04, final_wd=0.4, T_max=112500)
+    probe = {int(k): i for i, k in enumerate(t["sched_steps"])}
+    for step in range(1, int(t["sched_steps"][-1]) + 1):
+        a, b = s.step(), w.step()
+        if step in probe:
+            assert a == t["sched_lr"][probe[step]] and b == t["sched_wd"][probe[step]]
+    assert o.param_groups[0]["weight_decay"] == b and o.param_groups[1]["weight_decay"] == 0
+
+
+def test_repeat_interleave_batch():
+    from jepa_amd.src.utils.tensors import repeat_interleave_batch
+    x = torch.arange(12).reshape(6, 2)
+    out = repeat_interleave_batch(x, 2, repeat=3)
+    exp = torch.cat([torch.cat([x[i * 2:(i + 1) * 2] for _ in range(3)], 0) for i in range(3)], 0)
+    assert torch.equal(out, exp)
+    assert torch.equal(repeat_interleave_batch(x, 2, repeat=1), x)
+
+
+@pytest.mark.reference
+def test_init_video_model_is_seed_for_seed_identical_to_reference():
+    import importlib
+    saved = {k: v for k, v in sys.modules.items() if k == "src" or k.startswith("src.") or k == "app" or k.startswith("app.")}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, "/root/reference")
+    try:
+        ref_init = importlib.import_module("app.vjepa.utils").init_video_model
+    finally:
+        sys.path.remove("/root/reference")
+    from jepa_amd.app.vjepa.utils import init_video_model
+    kw = dict(device="cpu", patch_size=16, num_frames=8, tubelet_size=2, model_name="vit_tiny", crop_size=64,
+              pred_depth=2, pred_embed_dim=96, uniform_power=True, use_mask_tokens=True, num_mask_tokens=2,
+              zero_init_mask_tokens=True, use_sdpa=True)
+    torch.manual_seed(0)
+    re, rp = ref_init(**kw)
+    torch.manual_seed(0)
+    oe, op = init_video_model(**kw)
+    for ref, ours in ((re, oe), (rp, op)):
+        rs, os_ = ref.state_dict(), ours.state_dict()
+        assert list(rs.keys()) == list(os_.keys())
+        for k in rs:
+            assert rs[k].shape == os_[k].shape, k
+            assert torch.equal(rs[k], os_[k]), k
+        assert [n for n, p in ref.named_parameters() if p.requires_grad] == \
+            [n for n, p in ours.named_parameters() if p.requires_grad]
+    for attr in ("embed_dim", "num_heads", "num_patches", "patch_size", "tubelet_size", "num_frames", "input_size"):
+        assert getattr(re.backbone, attr) == getattr(oe.backbone, attr)
