@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""V-JEPA pretraining-step benchmark on MI355X (BASELINE.json metric: clips/sec, fwd+bwd+EMA, ViT-L/16 16x224x224).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (reference app/vjepa/train.py:414-487: schedules, target forward,
+context+predictor forward/backward, latent loss, gradient all-reduce, AdamW, EMA) over one batch of synthetic
+clips already resident in HBM, with mask indices drawn by the reference-compatible multiblock collator.
+Weak scaling: every rank processes its own B=24 clips.  Rank 0 prints ONE JSON line.
+
+`roofline` is read on the dominant kernel family (the bf16 MFMA GEMM): algorithmic 2*M*N*K of every launch
+divided by its duration measured with HIP events on the launch stream, in an instrumented pass of the same
+workload run right after the un-instrumented timed region (`value` never includes instrumentation).
+`cpu_baseline` times the pinned CPU oracle (a port of the reference arithmetic) on the host cores, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VITL_MASKS = [  # configs/pretrain/vitl16.yaml:38-62
+    dict(aspect_ratio=(0.75, 1.5), num_blocks=8, spatial_scale=(0.15, 0.15), temporal_scale=(1.0, 1.0),
+         max_temporal_keep=1.0, max_keep=None),
+    dict(aspect_ratio=(0.75, 1.5), num_blocks=2, spatial_scale=(0.7, 0.7), temporal_scale=(1.0, 1.0),
+         max_temporal_keep=1.0, max_keep=None),
+]
+WORKLOADS = {
+    "vitl16": dict(model_name="vit_large", crop=224, frames=16, patch=16, tubelet=2, pred_depth=12, pred_dim=384,
+                   batch=24, embed_dim=1024, depth=24, masks=VITL_MASKS,
+                   desc="V-JEPA pretrain step ViT-L/16 16x224x224, B=24/GPU, 2 multiblock masks (vitl16.yaml)"),
+    "vith16": dict(model_name="vit_huge", crop=224, frames=16, patch=16, tubelet=2, pred_depth=12, pred_dim=384,
+                   batch=24, embed_dim=1280, depth=32, masks=VITL_MASKS,
+                   desc="V-JEPA pretrain step ViT-H/16 16x224x224, B=24/GPU, 2 multiblock masks"),
+    "vittiny": dict(model_name="vit_tiny", crop=64, frames=8, patch=16, tubelet=2, pred_depth=2, pred_dim=96,
+                    batch=2, embed_dim=192, depth=12, masks=VITL_MASKS[:1],
+                    desc="V-JEPA pretrain step ViT-Tiny/16 8x64x64, B=2, 1 mask (plumbing config)"),
+}
+HP = dict(ipe=300, ipe_scale=1.25, epochs=300, warmup=40, start_lr=2e-4, lr=6.25e-4, final_lr=1e-6, wd=0.04,
+          final_wd=0.4, ema=(0.998, 1.0), betas=(0.9, 0.999), eps=1e-8, loss_exp=1.0, reg_coeff=0.0)
+MFMA_BF16_PEAK = 2.5e15  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def build(wl, device, world_size):
+    import copy
+    from jepa_amd.app.vjepa.utils import init_opt, init_video_model
+    torch.manual_seed(0)
+    enc, pred = init_video_model(device="cpu", patch_size=wl["patch"], num_frames=wl["frames"],
+                                 tubelet_size=wl["tubelet"], model_name=wl["model_name"], crop_size=wl["crop"],
+                                 pred_depth=wl["pred_depth"], pred_embed_dim=wl["pred_dim"], uniform_power=True,
+                                 use_mask_tokens=True, num_mask_tokens=len(wl["masks"]), zero_init_mask_tokens=True,
+                                 use_sdpa=True)
+    tgt = copy.deepcopy(enc)
+    for p in tgt.parameters():
+        p.requires_grad = False
+    trainer, _, sched, wd_sched = init_opt(
+        encoder=enc, predictor=pred, target_encoder=tgt, wd=HP["wd"], final_wd=HP["final_wd"],
+        start_lr=HP["start_lr"], ref_lr=HP["lr"], final_lr=HP["final_lr"], iterations_per_epoch=HP["ipe"],
+        warmup=HP["warmup"], num_epochs=HP["epochs"], ipe_scale=HP["ipe_scale"], mixed_precision=True,
+        betas=HP["betas"], eps=HP["eps"], loss_exp=HP["loss_exp"], reg_coeff=HP["reg_coeff"], clip_grad=10.0,
+        world_size=world_size, device=device)
+    return trainer, sched, wd_sched
+
+
+def make_inputs(wl, n_steps, rank, device):
+    from jepa_amd.src.masks.multiblock3d import MaskCollator
+    coll = MaskCollator(cfgs_mask=wl["masks"], crop_size=wl["crop"], num_frames=wl["frames"],
+                        patch_size=wl["patch"], tubelet_size=wl["tubelet"])
+    B = wl["batch"]
+    batches = []
+    gen = torch.Generator(device=device)
+    for step in range(n_steps):
+        gen.manual_seed(1234 + step + 1000 * rank)
+        clips = torch.randn(B, 3, wl["frames"], wl["crop"], wl["crop"], device=device, generator=gen)  # never zeros
+        torch.manual_seed(4321 + step + 1000 * rank)
+        _, me, mp = coll([(torch.zeros(1), 0) for _ in range(B)])
+        batches.append((clips, [m.to(device) for m in me], [m.to(device) for m in mp]))
+    return batches
+
+
+def cpu_baseline(wl_name):
+    """Pinned oracle (CPU port of the reference arithmetic) on a bounded sample of the same workload."""
+    from oracle import vjepa_oracle as O
+    wl = WORKLOADS[wl_name]
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    B = 2
+    from jepa_amd.app.vjepa.utils import init_video_model
+    torch.manual_seed(0)
+    enc, pred = init_video_model(device="cpu", patch_size=wl["patch"], num_frames=wl["frames"],
+                                 tubelet_size=wl["tubelet"], model_name=wl["model_name"], crop_size=wl["crop"],
+                                 pred_depth=wl["pred_depth"], pred_embed_dim=wl["pred_dim"], uniform_power=True,
+                                 use_mask_tokens=True, num_mask_tokens=len(wl["masks"]), zero_init_mask_tokens=True)
+    heads = enc.backbone.num_heads
+    cfg = dict(embed_dim=wl["embed_dim"], depth=wl["depth"], heads=heads, pred_dim=wl["pred_dim"],
+               pred_depth=wl["pred_depth"], num_mask_tokens=len(wl["masks"]), patch=wl["patch"],
+               tubelet=wl["tubelet"], num_patches=enc.backbone.num_patches)
+    ew = {k[len("backbone."):]: v.detach().clone() for k, v in enc.state_dict().items()}
+    pw = {k[len("backbone."):]: v.detach().clone() for k, v in pred.state_dict().items()}
+    state = dict(enc=ew, pred=pw, tgt={k: v.clone() for k, v in ew.items()}, opt={})
+    gens = O.make_mask_gens(wl["masks"], wl["crop"], wl["frames"], wl["patch"], wl["tubelet"])
+    hp = dict(HP)
+    times = []
+    n_timed = 2 if wl_name != "vittiny" else 10
+    for step in range(1, 2 + n_timed):
+        clips = torch.randn(B, 3, wl["frames"], wl["crop"], wl["crop"], generator=torch.Generator().manual_seed(step))
+        torch.manual_seed(4321 + step)
+        me, mp = zip(*[g(B) for g in gens])
+        t0 = time.time()
+        O.train_step(state, clips, list(me), list(mp), cfg, hp, step)
+        if step > 1:
+            times.append(time.time() - t0)
+    v = B / (sum(times) / len(times))
+    return {"value": round(v, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU fp32 restatement of train.py:414-487), same model/masks, B={B}, 1 warm-up + "
+                      f"{n_timed} timed steps, torch CPU kernels with {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="vitl16", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (default: the recipe's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the V-JEPA step runs only in libvjepa_hip.so (no CPU path)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from jepa_amd.engine import dp
+    from jepa_amd.engine.flops import step_flops
+    from jepa_amd.hip import ops
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    trainer, sched, wd_sched = build(wl, device, world)
+    dp.broadcast_parameters(trainer.arena, trainer.tarena)
+    if world > 1:
+        trainer.sync_shadows()
+    n_total = args.warmup + args.steps
+    batches = make_inputs(wl, n_total, rank, device)
+    ema0, ema1 = HP["ema"]
+    mom = [ema0 + i * (ema1 - ema0) / (HP["ipe"] * HP["epochs"] * HP["ipe_scale"]) for i in range(n_total + 8)]
+
+    def run(i):
+        clips, me, mp = batches[i % len(batches)]
+        return trainer.train_step(clips, me, mp, lr=sched.step(), wd=wd_sched.step(), ema=mom[i])
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for i in range(args.warmup):
+        last = run(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_total):
+        last = run(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = last.loss
+    B = wl["batch"]
+    kpe = 3 * wl["tubelet"] * wl["patch"] ** 2
+    N = (wl["frames"] // wl["tubelet"]) * (wl["crop"] // wl["patch"]) ** 2
+    fl = 0.0
+    for i in range(args.warmup, n_total):
+        _, me, mp = batches[i % len(batches)]
+        fl += step_flops(wl["embed_dim"], wl["depth"], wl["pred_dim"], wl["pred_depth"], N, kpe, B,
+                         [m.shape[1] for m in me], [m.shape[1] for m in mp])
+    step_tflops = fl / elapsed / 1e12  # per GPU
+
+    roof = None
+    if not args.no_roofline_pass:
+        ops.KERNEL_TIMERS = {}
+        n_inst = min(3, args.steps)
+        for i in range(n_inst):
+            run(args.warmup + i)
+        sync()
+        timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
+        fam = {}
+        for name, evs in timers.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in evs)
+            fam[name] = dict(launches=len(evs), ms=ms, flop=sum(w for _, _, w in evs))
+        g = fam["gemm_nt"]
+        ach = g["flop"] / (g["ms"] * 1e-3)
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<64,*> (bf16 MFMA 16x16x32, LDS-DMA staged)",
+                "achieved": round(ach / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_BF16_PEAK, 4), "traffic": None,
+                "launches_per_step": g["launches"] // n_inst,
+                "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+                "gemm_ms_per_step": round(g["ms"] / n_inst, 2),
+                "attn_fwd": {"tflops": round(fam["attn_fwd"]["flop"] / fam["attn_fwd"]["ms"] / 1e9, 1),
+                             "ms_per_step": round(fam["attn_fwd"]["ms"] / n_inst, 2)},
+                "attn_bwd": {"tflops": round(fam["attn_bwd"]["flop"] / fam["attn_bwd"]["ms"] / 1e9, 1),
+                             "ms_per_step": round(fam["attn_bwd"]["ms"] / n_inst, 2)},
+                "whole_step": {"achieved": round(step_tflops, 2), "frac": round(step_tflops * 1e12 / MFMA_BF16_PEAK, 4),
+                               "tflop_per_clip": round(fl / (args.steps * B) / 1e12, 3)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload)
+
+    if rank == 0:
+        line = {
+            "metric": "V-JEPA pretrain clips/sec (fwd+bwd+EMA)", "value": round(B * world * args.steps / elapsed, 3),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": wl["desc"], "global_batch": B * world, "per_gpu_batch": B,
+                       "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,279 @@
+"""V-JEPA pretraining loop with the reference's entry point and YAML schema (app/vjepa/train.py:66-586):
+
+    from jepa_amd.app.vjepa.train import main
+    main(args_dict_from_yaml, resume_preempt=False)
+
+Same config keys, schedules, momentum generator, CSV columns, checkpoint dictionary and state-dict key names
+(`module.backbone.*`, as written by the reference's DDP-wrapped modules) -- but `train_step` is the fused MI355X
+step of jepa_amd.engine.step.Trainer (hand-written gfx950 kernels, no autograd, RCCL gradient all-reduce
+overlapped with backward) instead of autocast + DDP + torch.optim.AdamW + a per-tensor EMA loop.
+"""
+import copy
+import os
+import time
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from ...engine import dp
+from ...src.datasets.data_manager import init_data
+from ...src.masks.multiblock3d import MaskCollator as MB3DMaskCollator
+from ...src.masks.random_tube import MaskCollator as TubeMaskCollator
+from ...src.utils.distributed import AllReduce, init_distributed
+from ...src.utils.logging import AverageMeter, CSVLogger, get_logger, gpu_timer
+from ...src.utils.tensors import repeat_interleave_batch
+from .utils import init_opt, init_video_model, load_checkpoint
+
+log_timings = True
+log_freq = 10
+checkpoint_freq = 1
+
+_GLOBAL_SEED = 0
+np.random.seed(_GLOBAL_SEED)
+torch.manual_seed(_GLOBAL_SEED)
+
+logger = get_logger(__name__)
+
+
+def _with_module_prefix(sd):
+    return {"module." + k: v for k, v in sd.items()}
+
+
+def main(args, resume_preempt=False):
+    # ----------------------------------------------------------------------- config (train.py:71-157)
+    cfgs_meta = args.get('meta')
+    load_model = cfgs_meta.get('load_checkpoint') or resume_preempt
+    r_file = cfgs_meta.get('read_checkpoint', None)
+    seed = cfgs_meta.get('seed', _GLOBAL_SEED)
+    save_every_freq = cfgs_meta.get('save_every_freq', -1)
+    skip_batches = cfgs_meta.get('skip_batches', -1)
+    use_sdpa = cfgs_meta.get('use_sdpa', False)
+    which_dtype = cfgs_meta.get('dtype')
+    logger.info(f'{which_dtype=}')
+    if which_dtype.lower() != 'bfloat16':
+        raise NotImplementedError("meta.dtype must be bfloat16: the MI355X path computes in bf16 MFMA with fp32 "
+                                  "accumulation and fp32 master weights (every shipped pretrain config uses bfloat16)")
+    mixed_precision = True
+
+    cfgs_mask = args.get('mask')
+    cfgs_model = args.get('model')
+    model_name = cfgs_model.get('model_name')
+    pred_depth = cfgs_model.get('pred_depth')
+    pred_embed_dim = cfgs_model.get('pred_embed_dim')
+    uniform_power = cfgs_model.get('uniform_power', True)
+    use_mask_tokens = cfgs_model.get('use_mask_tokens', True)
+    zero_init_mask_tokens = cfgs_model.get('zero_init_mask_tokens', True)
+
+    cfgs_data = args.get('data')
+    dataset_type = cfgs_data.get('dataset_type', 'videodataset')
+    mask_type = cfgs_data.get('mask_type', 'multiblock3d')
+    dataset_paths = cfgs_data.get('datasets', [])
+    datasets_weights = cfgs_data.get('datasets_weights', None)
+    if datasets_weights is not None:
+        assert len(datasets_weights) == len(dataset_paths), 'Must have one sampling weight specified for each dataset'
+    batch_size = cfgs_data.get('batch_size')
+    num_clips = cfgs_data.get('num_clips')
+    num_frames = cfgs_data.get('num_frames')
+    tubelet_size = cfgs_data.get('tubelet_size')
+    sampling_rate = cfgs_data.get('sampling_rate')
+    duration = cfgs_data.get('clip_duration', None)
+    crop_size = cfgs_data.get('crop_size', 224)
+    patch_size = cfgs_data.get('patch_size')
+    pin_mem = cfgs_data.get('pin_mem', False)
+    num_workers = cfgs_data.get('num_workers', 1)
+    filter_short_videos = cfgs_data.get('filter_short_videos', False)
+    decode_one_clip = cfgs_data.get('decode_one_clip', True)
+
+    cfgs_loss = args.get('loss')
+    loss_exp = cfgs_loss.get('loss_exp')
+    reg_coeff = cfgs_loss.get('reg_coeff')
+
+    cfgs_opt = args.get('optimization')
+    ipe = cfgs_opt.get('ipe', None)
+    ipe_scale = cfgs_opt.get('ipe_scale', 1.0)
+    clip_grad = cfgs_opt.get('clip_grad', None)
+    wd = float(cfgs_opt.get('weight_decay'))
+    final_wd = float(cfgs_opt.get('final_weight_decay'))
+    num_epochs = cfgs_opt.get('epochs')
+    warmup = cfgs_opt.get('warmup')
+    start_lr = cfgs_opt.get('start_lr')
+    lr = cfgs_opt.get('lr')
+    final_lr = cfgs_opt.get('final_lr')
+    ema = cfgs_opt.get('ema')
+    betas = cfgs_opt.get('betas', (0.9, 0.999))
+    eps = cfgs_opt.get('eps', 1.e-8)
+
+    cfgs_logging = args.get('logging')
+    folder = cfgs_logging.get('folder')
+    tag = cfgs_logging.get('write_tag')
+
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    try:
+        mp.set_start_method('spawn')
+    except Exception:
+        pass
+
+    world_size, rank = init_distributed()
+    logger.info(f'Initialized (rank/world-size) {rank}/{world_size}')
+    if not torch.cuda.is_available():
+        raise RuntimeError("jepa_amd.app.vjepa.train needs an MI355X: the step runs only in libvjepa_hip.so")
+    device = torch.device('cuda', torch.cuda.current_device())
+
+    os.makedirs(folder, exist_ok=True)
+    log_file = os.path.join(folder, f'{tag}_r{rank}.csv')
+    latest_path = os.path.join(folder, f'{tag}-latest.pth.tar')
+    load_path = None
+    if load_model:
+        load_path = os.path.join(folder, r_file) if r_file is not None else latest_path
+        if not os.path.exists(load_path):
+            load_path, load_model = None, False
+
+    csv_logger = CSVLogger(log_file, ('%d', 'epoch'), ('%d', 'itr'), ('%.5f', 'loss'), ('%.5f', 'loss-jepa'),
+                           ('%.5f', 'reg-loss'), ('%.5f', 'enc-grad-norm'), ('%.5f', 'pred-grad-norm'),
+                           ('%d', 'gpu-time(ms)'), ('%d', 'wall-time(ms)'))
+
+    encoder, predictor = init_video_model(
+        uniform_power=uniform_power, use_mask_tokens=use_mask_tokens, num_mask_tokens=len(cfgs_mask),
+        zero_init_mask_tokens=zero_init_mask_tokens, device='cpu', patch_size=patch_size, num_frames=num_frames,
+        tubelet_size=tubelet_size, model_name=model_name, crop_size=crop_size, pred_depth=pred_depth,
+        pred_embed_dim=pred_embed_dim, use_sdpa=use_sdpa)
+    target_encoder = copy.deepcopy(encoder)
+    for p in target_encoder.parameters():
+        p.requires_grad = False
+
+    collator_cls = MB3DMaskCollator if mask_type == 'multiblock3d' else TubeMaskCollator
+    mask_collator = collator_cls(crop_size=crop_size, num_frames=num_frames, patch_size=patch_size,
+                                 tubelet_size=tubelet_size, cfgs_mask=cfgs_mask)
+
+    (unsupervised_loader, unsupervised_sampler) = init_data(
+        data=dataset_type, root_path=dataset_paths, batch_size=batch_size, training=True, clip_len=num_frames,
+        frame_sample_rate=sampling_rate, filter_short_videos=filter_short_videos, decode_one_clip=decode_one_clip,
+        duration=duration, num_clips=num_clips, transform=None, datasets_weights=datasets_weights,
+        collator=mask_collator, num_workers=num_workers, world_size=world_size, pin_mem=pin_mem, rank=rank,
+        log_dir=None, crop_size=crop_size)
+    try:
+        _dlen = len(unsupervised_loader)
+    except Exception:
+        _dlen = unsupervised_loader.num_batches
+    if ipe is None:
+        ipe = _dlen
+    logger.info(f'iterations per epoch/dataest length: {ipe}/{_dlen}')
+
+    optimizer, scaler, scheduler, wd_scheduler = init_opt(
+        encoder=encoder, predictor=predictor, target_encoder=target_encoder, wd=wd, final_wd=final_wd,
+        start_lr=start_lr, ref_lr=lr, final_lr=final_lr, iterations_per_epoch=ipe, warmup=warmup,
+        num_epochs=num_epochs, ipe_scale=ipe_scale, mixed_precision=mixed_precision, betas=betas, eps=eps,
+        loss_exp=loss_exp, reg_coeff=reg_coeff, clip_grad=clip_grad, world_size=world_size, device=device)
+    trainer = optimizer
+    dp.broadcast_parameters(trainer.arena, trainer.tarena)   # DDP's one-time parameter sync (train.py:295-297)
+    if world_size > 1:
+        trainer.sync_shadows()
+
+    momentum_scheduler = (ema[0] + i * (ema[1] - ema[0]) / (ipe * num_epochs * ipe_scale)
+                          for i in range(int(ipe * num_epochs * ipe_scale) + 1))
+
+    start_epoch = 0
+    if load_model or os.path.exists(latest_path):
+        encoder, predictor, target_encoder, optimizer, scaler, start_epoch = load_checkpoint(
+            r_path=load_path if load_path is not None else latest_path, encoder=encoder, predictor=predictor,
+            target_encoder=target_encoder, opt=optimizer, scaler=scaler)
+        for _ in range(start_epoch * ipe):   # replay schedules and the mask counter (train.py:322-326)
+            scheduler.step()
+            wd_scheduler.step()
+            next(momentum_scheduler)
+            mask_collator.step()
+
+    def save_checkpoint(epoch, path):
+        if rank != 0:
+            return
+        save_dict = {
+            'encoder': _with_module_prefix(encoder.state_dict()),
+            'predictor': _with_module_prefix(predictor.state_dict()),
+            'opt': optimizer.state_dict(),
+            'scaler': None if scaler is None else scaler.state_dict(),
+            'target_encoder': _with_module_prefix(target_encoder.state_dict()),
+            'epoch': epoch, 'loss': loss_meter.avg, 'batch_size': batch_size, 'world_size': world_size, 'lr': lr,
+        }
+        try:
+            torch.save(save_dict, path)
+        except Exception as e:
+            logger.info(f'Encountered exception when saving checkpoint: {e}')
+
+    logger.info('Initializing loader...')
+    loader = iter(unsupervised_loader)
+    if skip_batches > 0:
+        unsupervised_sampler.set_epoch(start_epoch)
+        for itr in range(skip_batches):
+            try:
+                next(loader)
+            except Exception:
+                loader = iter(unsupervised_loader)
+                next(loader)
+
+    for epoch in range(start_epoch, num_epochs):
+        logger.info('Epoch %d' % (epoch + 1))
+        unsupervised_sampler.set_epoch(epoch)
+        loss_meter, input_var_meter, input_var_min_meter = AverageMeter(), AverageMeter(), AverageMeter()
+        jepa_loss_meter, reg_loss_meter = AverageMeter(), AverageMeter()
+        mask_meters = [AverageMeter() for _ in range(len(cfgs_mask))]
+        gpu_time_meter, wall_time_meter = AverageMeter(), AverageMeter()
+
+        for itr in range(ipe):
+            itr_start_time = time.time()
+            try:
+                udata, masks_enc, masks_pred = next(loader)
+            except Exception:
+                logger.info('Exhausted data loaders. Refreshing...')
+                loader = iter(unsupervised_loader)
+                udata, masks_enc, masks_pred = next(loader)
+            assert len(masks_enc) == len(masks_pred), 'Currently require num encoder masks = num predictor masks'
+
+            clips = torch.cat([u.to(device, non_blocking=True) for u in udata[0]], dim=0)
+            masks_enc = [repeat_interleave_batch(m.to(device, non_blocking=True), batch_size, repeat=num_clips)
+                         for m in masks_enc]
+            masks_pred = [repeat_interleave_batch(m.to(device, non_blocking=True), batch_size, repeat=num_clips)
+                          for m in masks_pred]
+            for _i, m in enumerate(mask_meters):
+                m.update(masks_enc[_i][0].size(-1))
+
+            def train_step():
+                _new_lr = scheduler.step()
+                _new_wd = wd_scheduler.step()
+                m = next(momentum_scheduler)
+                out = trainer.train_step(clips, masks_enc, masks_pred, lr=_new_lr, wd=_new_wd, ema=m,
+                                         clip_now=(epoch > warmup) and (clip_grad is not None))
+                return (out.loss, out.loss_jepa, out.loss_reg, _new_lr, _new_wd, out.grad_norms)
+
+            (loss, loss_jepa, loss_reg, _new_lr, _new_wd, grad_norms), gpu_etime_ms = gpu_timer(train_step)
+            iter_elapsed_time_ms = (time.time() - itr_start_time) * 1000.
+            loss_meter.update(loss)
+            if itr % log_freq == 0:   # input statistics only when they are printed (one fused reduction each)
+                flat = clips.view(clips.shape[0], -1)
+                input_var = float(AllReduce.apply(flat.var(dim=1).mean(dim=0)))
+                input_var_min = float(AllReduce.apply(torch.min(flat.var(dim=1))))
+                input_var_meter.update(input_var)
+                input_var_min_meter.update(input_var_min)
+            jepa_loss_meter.update(loss_jepa)
+            reg_loss_meter.update(loss_reg)
+            gpu_time_meter.update(gpu_etime_ms)
+            wall_time_meter.update(iter_elapsed_time_ms)
+
+            csv_logger.log(epoch + 1, itr, loss, loss_jepa, loss_reg, grad_norms[0], grad_norms[1], gpu_etime_ms,
+                           iter_elapsed_time_ms)
+            if (itr % log_freq == 0) or np.isnan(loss) or np.isinf(loss):
+                logger.info('[%d, %5d] loss: %.3f | p%.3f r%.3f | input_var: %.3f %.3f | masks: %s '
+                            '[wd: %.2e] [lr: %.2e] [mem: %.2e] [gpu: %.1f ms][wall: %.1f ms]'
+                            % (epoch + 1, itr, loss_meter.avg, jepa_loss_meter.avg, reg_loss_meter.avg,
+                               input_var_meter.avg, input_var_min_meter.avg,
+                               '[' + ', '.join(['%.1f' % m.avg for m in mask_meters]) + ']', _new_wd, _new_lr,
+                               torch.cuda.max_memory_allocated() / 1024.0 ** 2, gpu_time_meter.avg,
+                               wall_time_meter.avg))
+            assert not np.isnan(loss), 'loss is nan'
+
+        logger.info('avg. loss %.3f' % loss_meter.avg)
+        if epoch % checkpoint_freq == 0 or epoch == (num_epochs - 1):
+            save_checkpoint(epoch + 1, latest_path)
+            if save_every_freq > 0 and epoch % save_every_freq == 0:
+                save_checkpoint(epoch + 1, os.path.join(folder, f'{tag}-e{epoch}.pth.tar'))

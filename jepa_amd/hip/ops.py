@@ -144,6 +144,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, alpha=1.0,
 
 # ---------------------------------------------------------------- gemm
 GEMM_FLAGS = 0  # bit0: register-staged operands instead of LDS-DMA (set by tests for A/B runs)
+KERNEL_TIMERS = None  # bench.py sets this to a dict: name -> list of (start_event, end_event, work) on the launch stream
+
+
+def _timed(name, work):
+    """Context helper: HIP events around one launch on the stream the kernel is enqueued on."""
+    if KERNEL_TIMERS is None:
+        return None
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    KERNEL_TIMERS.setdefault(name, []).append((s, e, work))
+    s.record()
+    return e
 
 
 def gemm_nt(A, B, out=None, bias=None, residual=None, aux_in=None, aux_out=None, epilogue=EPI_BF16, alpha=1.0,
@@ -159,10 +170,13 @@ def gemm_nt(A, B, out=None, bias=None, residual=None, aux_in=None, aux_out=None,
     if out is None:
         out = torch.empty((M, N), dtype=F32 if epilogue == EPI_F32 else BF16, device=A.device)
     aux = aux_in if aux_in is not None else aux_out
+    _ev = _timed("gemm_nt", 2.0 * M * N * K)
     check(lib.vj_gemm_bf16_nt(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), M, N, K,
                               _ptr(bias), _ptr(residual), 0 if residual is None else residual.stride(0),
                               _ptr(aux_in), _ptr(aux_out), 0 if aux is None else aux.stride(0), epilogue, alpha, beta,
                               GEMM_FLAGS if flags is None else flags, _stream(stream)), "vj_gemm_bf16_nt")
+    if _ev is not None:
+        _ev.record()
     return out
 
 
@@ -205,7 +219,10 @@ def attn_fwd(qkv, B, S, H, hd, scale, save_lse=True, out=None, stream=None):
     _req(qkv, BF16, "qkv")
     o = torch.empty((B * S, H * hd), dtype=BF16, device=qkv.device) if out is None else out
     lse = torch.empty((B, H, S), dtype=F32, device=qkv.device) if save_lse else None
+    _ev = _timed("attn_fwd", 4.0 * B * H * S * S * hd)
     check(lib.vj_attn_fwd(_ptr(qkv), _ptr(o), _ptr(lse), B, S, H, hd, scale, _stream(stream)), "vj_attn_fwd")
+    if _ev is not None:
+        _ev.record()
     return o, lse
 
 
@@ -215,8 +232,11 @@ def attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
     dqkv = torch.empty_like(qkv) if out is None else out
     nws = lib.vj_attn_bwd_ws_bytes(B, S, H)
     ws = Scratch.get(nws, qkv.device, "attn")
+    _ev = _timed("attn_bwd", 8.0 * B * H * S * S * hd)
     check(lib.vj_attn_bwd(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), B, S, H, hd, scale, _ptr(ws), nws,
                           _stream(stream)), "vj_attn_bwd")
+    if _ev is not None:
+        _ev.record()
     return dqkv
 
 
