@@ -76,9 +76,19 @@ int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
                     void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags,
                     vj_stream_t stream);
+/* wgrad form of the same GEMM: C (fp32) = alpha*A*B^T + beta*C where K (= tokens) is long and the [M,N] tile grid
+ * alone cannot fill 256 CUs: K is split across workgroups, partials combined deterministically from ws
+ * (ws_bytes >= M*N*4; more workspace allows more slices). */
+int vj_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                           int64_t N, int64_t K, float alpha, float beta, int flags, void* ws, int64_t ws_bytes,
+                           vj_stream_t stream);
 /* out[N, Mpad] = in[M,N]^T (zero padded): the wgrad operands dY^T, X^T; weight shadows W^T for dgrad. */
 int vj_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,
                       vj_stream_t stream);
+/* transpose + bias gradient in ONE pass over dY: colsum[n] = alpha*sum_m in[m][n] + beta*colsum[n] */
+int64_t vj_transpose_colsum_ws_bytes(int64_t M, int64_t N);
+int vj_transpose_colsum_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,
+                             float* colsum, float alpha, float beta, void* ws, int64_t ws_bytes, vj_stream_t stream);
 /* bias / mask-token gradients: out[n] = alpha * sum_{m: row_lo <= m % group < row_hi} in[m][n] + beta*out[n] */
 int64_t vj_colsum_ws_bytes(int64_t N);
 int vj_colsum_bf16(const void* in, int64_t M, int64_t N, int64_t ld, int64_t group, int64_t row_lo, int64_t row_hi,

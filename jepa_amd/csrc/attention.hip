@@ -193,29 +193,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       }
     // ---- online softmax (query = li, reduced over r, kt in-lane and over g across lanes 16/32 apart) ----
     bf16x8_t pf[2][2];
+    const bool tail = (k0 + 64 > S);  // wave-uniform: only the last tile can hold padded keys
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
+      if (tail) {
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (k0 + kt * 16 + 4 * g + r >= S) sacc[qt][kt][r] = -INFINITY;
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int key = k0 + kt * 16 + 4 * g + r;
-          float s = sacc[qt][kt][r] * sc;
-          s = key < S ? s : -INFINITY;
-          sacc[qt][kt][r] = s;
-          mx = fmaxf(mx, s);
-        }
+        for (int r = 0; r < 4; r++) mx = fmaxf(mx, sacc[qt][kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = exp2f(mrun[qt] - mnew);
+      const float mnew = fmaxf(mrun[qt], mx * sc);   // sc > 0: max commutes with the scaling
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
       float ls = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; kt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const float p = exp2f(sacc[qt][kt][r] - mnew);
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][kt][r], sc, -mnew));
           sacc[qt][kt][r] = p;
           ls += p;
         }
@@ -387,8 +389,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int q = qt * 16 + 4 * g + r;
-        float p = exp2f(sacc[r] * sc - lse_s[q]);
-        p = key_ok ? p : 0.f;
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -lse_s[q]));  // padded queries: lse = +inf -> 0
         pv[qt][r] = p;
         dsv[qt][r] = p * (dpacc[r] - dl_s[q]);
       }
@@ -531,9 +532,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       for (int kt = 0; kt < 4; kt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int key = k0 + kt * 16 + 4 * g + r;
-          float p = exp2f(sacc[qt][kt][r] * sc - lse_q[qt]);
-          p = key < S ? p : 0.f;
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][kt][r], sc, -lse_q[qt]));
           sacc[qt][kt][r] = p * (dpacc[qt][kt][r] - dl_q[qt]);
         }
 #pragma unroll

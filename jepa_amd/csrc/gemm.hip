@@ -28,6 +28,9 @@ struct GemmArgs {
   int64_t M, N, K, lda, ldb, ldc, ldr, ldaux;
   float alpha, beta;
   int tiles_m, tiles_n;
+  int splitk;          // > 1: K is cut into `splitk` slices, raw fp32 partials go to ws[slice][M][N] (EPI_F32 only)
+  int ktiles_per;      // K-tiles per slice
+  float* ws;
 };
 
 #define BM 128
@@ -84,10 +87,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   const int wm = wave_u >> 1, wn = wave_u & 1;
 
   // ---- XCD-aware, grouped tile mapping (bijective for any grid size) ----
-  const int nblk = p.tiles_m * p.tiles_n;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int nblk = ntile * p.splitk;
   const int bid = blockIdx.x;
   const int qx = nblk >> 3, rx = nblk & 7, xcd = bid & 7, pos = bid >> 3;
-  const int logical = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + pos;
+  const int logical_all = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + pos;
+  const int slice = logical_all / ntile;
+  const int logical = logical_all - slice * ntile;
   constexpr int GM = 8;
   const int per_group = GM * p.tiles_n;
   const int group = logical / per_group, in_g = logical - group * per_group;
@@ -102,7 +108,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (int)(p.K / BK);
+  const int nk_all = (int)(p.K / BK);
+  const int kt0 = slice * p.ktiles_per;
+  const int kt1 = (kt0 + p.ktiles_per) < nk_all ? (kt0 + p.ktiles_per) : nk_all;
   u32x4_t ra[NIT], rb[NIT];
 
   // fragment read offsets (bytes inside a tile), constant across K-tiles
@@ -118,20 +126,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
       b_off[i][ks] = rb_ * (BK * 2) + ((c ^ swz_of<BK>(rb_)) * 16);
     }
 
-  // prologue: stage tile 0 into buffer 0
-  stage_issue<BK, GLDS>(p.A, p.lda, m0, p.M, 0, smem, tid, wave_u, ra);
-  stage_issue<BK, GLDS>(p.B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, tid, wave_u, rb);
-  if constexpr (!GLDS) {
-    stage_commit<BK>(smem, tid, ra);
-    stage_commit<BK>(smem + TILE_BYTES, tid, rb);
+  // prologue: stage this slice's first K-tile into buffer 0
+  if (kt0 < kt1) {
+    stage_issue<BK, GLDS>(p.A, p.lda, m0, p.M, (int64_t)kt0 * BK, smem, tid, wave_u, ra);
+    stage_issue<BK, GLDS>(p.B, p.ldb, n0, p.N, (int64_t)kt0 * BK, smem + TILE_BYTES, tid, wave_u, rb);
+    if constexpr (!GLDS) {
+      stage_commit<BK>(smem, tid, ra);
+      stage_commit<BK>(smem + TILE_BYTES, tid, rb);
+    }
   }
 
-  for (int kt = 0; kt < nk; kt++) {
-    char* cur = smem + (kt & 1) * (2 * TILE_BYTES);
-    char* nxt = smem + ((kt + 1) & 1) * (2 * TILE_BYTES);
+  for (int kt = kt0; kt < kt1; kt++) {
+    char* cur = smem + ((kt - kt0) & 1) * (2 * TILE_BYTES);
+    char* nxt = smem + ((kt - kt0 + 1) & 1) * (2 * TILE_BYTES);
     if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt is in LDS for every wave; every wave is done reading tile kt-1
-    if (kt + 1 < nk) {
+    if (kt + 1 < kt1) {
       stage_issue<BK, GLDS>(p.A, p.lda, m0, p.M, (int64_t)(kt + 1) * BK, nxt, tid, wave_u, ra);
       stage_issue<BK, GLDS>(p.B, p.ldb, n0, p.N, (int64_t)(kt + 1) * BK, nxt + TILE_BYTES, tid, wave_u, rb);
     }
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if constexpr (!GLDS) {
-      if (kt + 1 < nk) {  // other buffer: nobody reads it until the next barrier
+      if (kt + 1 < kt1) {  // other buffer: nobody reads it until the next barrier
         stage_commit<BK>(nxt, tid, ra);
         stage_commit<BK>(nxt + TILE_BYTES, tid, rb);
       }
@@ -168,6 +178,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
       if (n >= p.N) continue;  // N % 4 == 0 is enforced by the host wrapper
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if constexpr (EPI == EPI_F32) {
+        if (p.splitk > 1) {  // raw partial; alpha/beta are applied by the slice reduction
+          *(float4*)(p.ws + ((int64_t)slice * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+          continue;
+        }
         float* cp = (float*)p.C + m * p.ldc + n;
         float4 o = make_float4(v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha);
         if (p.beta != 0.f) {
@@ -220,6 +234,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
+// out[m][n] = alpha * sum_s ws[s][m][n] + beta * out[m][n]   (deterministic split-K combine)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ ws, float* __restrict__ out,
+                                                            int64_t M, int64_t N, int64_t ldc, int S, float alpha,
+                                                            float beta) {
+  const int64_t n4 = M * N / 4, nq = N / 4;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    float4 acc = ws[q];
+    for (int s = 1; s < S; s++) {
+      const float4 v = ws[(int64_t)s * n4 + q];
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    const int64_t m = q / nq, n = (q - m * nq) * 4;
+    float* cp = out + m * ldc + n;
+    float4 o = make_float4(acc.x * alpha, acc.y * alpha, acc.z * alpha, acc.w * alpha);
+    if (beta != 0.f) {
+      const float4 c0 = *(const float4*)cp;
+      o.x += beta * c0.x;
+      o.y += beta * c0.y;
+      o.z += beta * c0.z;
+      o.w += beta * c0.w;
+    }
+    *(float4*)cp = o;
+  }
+}
+
 template <int BK, int EPI, bool GLDS>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   constexpr int smem = 2 * 2 * 128 * BK * 2;
@@ -228,9 +270,23 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, EPI, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  const int nblk = a.tiles_m * a.tiles_n;
-  hipLaunchKernelGGL((gemm_nt_kernel<BK, EPI, GLDS>), dim3(nblk), dim3(256), smem, stream, a);
+  GemmArgs b = a;
+  const int nk = (int)(a.K / BK);
+  if (b.splitk > nk) b.splitk = nk;
+  if (b.splitk < 1) b.splitk = 1;
+  b.ktiles_per = (nk + b.splitk - 1) / b.splitk;
+  b.splitk = (nk + b.ktiles_per - 1) / b.ktiles_per;  // no empty slices
+  const int nblk = a.tiles_m * a.tiles_n * b.splitk;
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, EPI, GLDS>), dim3(nblk), dim3(256), smem, stream, b);
   VJ_LAUNCH_CHECK("vj_gemm_bf16_nt");
+  if (b.splitk > 1) {
+    const int64_t n4 = a.M * a.N / 4;
+    int64_t g = cdiv64(n4, 256);
+    if (g > 256 * 8) g = 256 * 8;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float4*)a.ws,
+                       (float*)a.C, a.M, a.N, a.ldc, b.splitk, a.alpha, a.beta);
+    VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(splitk reduce)");
+  }
   return 0;
 }
 
@@ -242,10 +298,10 @@ static int dispatch_gemm(const GemmArgs& a, int flags, hipStream_t stream) {
 }
 
 // flags: bit0 = register-staged operand path instead of LDS-DMA (same numerics; for A/B testing)
-extern "C" int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                               int64_t M, int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr,
-                               const void* aux_in, void* aux_out, int64_t ldaux, int epilogue, float alpha,
-                               float beta, int flags, hipStream_t stream) {
+static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                      int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
+                      void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags, void* ws,
+                      int64_t ws_bytes, hipStream_t stream) {
   VJ_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "vj_gemm_bf16_nt: negative dim");
   if (M == 0 || N == 0) return 0;
   VJ_CHECK_ARG(K > 0 && K % 32 == 0, "vj_gemm_bf16_nt: K=%ld must be a positive multiple of 32 (pad the operands)", (long)K);
@@ -265,10 +321,39 @@ extern "C" int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.alpha = alpha; a.beta = beta;
   a.tiles_m = (int)cdiv64(M, BM); a.tiles_n = (int)cdiv64(N, BN);
+  a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
+  if (epilogue == EPI_F32 && ws != nullptr) {
+    // fill the chip: aim at >= 2 workgroups per CU; each slice keeps >= 8 K-tiles of work
+    const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+    int64_t s = cdiv64(512, tiles);
+    const int64_t max_by_k = (K / 64) / 8 > 0 ? (K / 64) / 8 : 1;
+    if (s > max_by_k) s = max_by_k;
+    while (s > 1 && s * M * N * 4 > ws_bytes) s--;
+    a.splitk = (int)s;
+    a.ws = (float*)ws;
+  }
   switch (epilogue) {
     case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, stream);
     case EPI_GELU: return dispatch_gemm<EPI_GELU>(a, flags, stream);
     case EPI_DGELU: return dispatch_gemm<EPI_DGELU>(a, flags, stream);
     default: return dispatch_gemm<EPI_F32>(a, flags, stream);
   }
+}
+
+extern "C" int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                               int64_t M, int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr,
+                               const void* aux_in, void* aux_out, int64_t ldaux, int epilogue, float alpha,
+                               float beta, int flags, hipStream_t stream) {
+  return gemm_entry(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, aux_in, aux_out, ldaux, epilogue, alpha, beta,
+                    flags, nullptr, 0, stream);
+}
+
+// wgrad form: C (fp32) = alpha * A B^T + beta * C with the long K (= tokens) dimension split across workgroups
+// when the [M,N] tile grid alone cannot fill 256 CUs; partials are combined deterministically from `ws`.
+extern "C" int vj_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                                      int64_t M, int64_t N, int64_t K, float alpha, float beta, int flags, void* ws,
+                                      int64_t ws_bytes, hipStream_t stream) {
+  VJ_CHECK_ARG(ws != nullptr && ws_bytes >= M * N * 4, "vj_gemm_bf16_nt_splitk: workspace must hold at least M*N fp32");
+  return gemm_entry(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, nullptr, 0, EPI_F32, alpha, beta,
+                    flags, ws, ws_bytes, stream);
 }

@@ -108,31 +108,36 @@ extern "C" int vj_layernorm_fwd(const void* x_bf16, const float* gamma, const fl
 // layernorm_bwd: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres], g = dy*gamma
 // per-block partial dgamma/dbeta in fp32 -> part[blk][0:D]=dgamma, part[blk][D:2D]=dbeta
 // ---------------------------------------------------------------------------------------------
-#define LN_BWD_BLOCKS 128
+#define LN_BWD_MAX_BLOCKS 1024
+template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in,
                                                             const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                             float* __restrict__ part, int64_t rows, int D) {
-  __shared__ float red[4][2 * 512 * LN_MAX_CHUNKS / 4];  // 4 waves x (dgamma|dbeta) staged per chunk pass
+  __shared__ float red[4][1024];  // 4 waves x (512 dgamma | 512 dbeta) staged per chunk pass
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float invD = 1.0f / (float)D;
-  float ag[LN_MAX_CHUNKS][8], ab[LN_MAX_CHUNKS][8];
+  float ag[NCH][8], ab[NCH][8], gam[NCH][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; i++)
+  for (int i = 0; i < NCH; i++) {
+    const int c = lane * 8 + i * 512;
 #pragma unroll
-    for (int j = 0; j < 8; j++) ag[i][j] = ab[i][j] = 0.f;
-
+    for (int j = 0; j < 8; j++) {
+      ag[i][j] = ab[i][j] = 0.f;
+      gam[i][j] = (c < D) ? gamma[c + j] : 0.f;
+    }
+  }
   const int64_t rows_per = cdiv64(rows, gridDim.x);
   const int64_t rbeg = (int64_t)blockIdx.x * rows_per;
   const int64_t rend = (rbeg + rows_per < rows) ? rbeg + rows_per : rows;
   for (int64_t r = rbeg + wv; r < rend; r += 4) {
     const float mean = mean_in[r], rstd = rstd_in[r];
-    float xh[LN_MAX_CHUNKS][8], g[LN_MAX_CHUNKS][8];
+    float xh[NCH][8], g[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+    for (int i = 0; i < NCH; i++) {
       const int c = lane * 8 + i * 512;
       if (c < D) {
         float xv[8], dv[8];
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           xh[i][j] = (xv[j] - mean) * rstd;
-          g[i][j] = dv[j] * gamma[c + j];
+          g[i][j] = dv[j] * gam[i][j];
           s1 += g[i][j];
           s2 += g[i][j] * xh[i][j];
           ag[i][j] += dv[j] * xh[i][j];
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     }
     const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+    for (int i = 0; i < NCH; i++) {
       const int c = lane * 8 + i * 512;
       if (c < D) {
         float o[8];
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   // cross-wave reduction of the column partials, one chunk pass at a time (512 columns x {dgamma,dbeta})
   float* pg = part + (int64_t)blockIdx.x * 2 * D;
 #pragma unroll
-  for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+  for (int i = 0; i < NCH; i++) {
     if (i * 512 < D) {
       __syncthreads();
 #pragma unroll
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   }
 }
 
-extern "C" int64_t vj_layernorm_bwd_ws_bytes(int64_t D) { return (int64_t)LN_BWD_BLOCKS * 2 * D * 4; }
+extern "C" int64_t vj_layernorm_bwd_ws_bytes(int64_t D) { return (int64_t)LN_BWD_MAX_BLOCKS * 2 * D * 4; }
 
 // dgamma/dbeta: out = alpha * sum + beta_acc * out   (beta_acc = 1 accumulates across calls)
 extern "C" int vj_layernorm_bwd(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
@@ -200,34 +205,22 @@ extern "C" int vj_layernorm_bwd(const void* dy_bf16, const void* x_bf16, const f
   VJ_CHECK_ARG(D % 8 == 0 && D <= 512 * LN_MAX_CHUNKS, "vj_layernorm_bwd: D=%ld unsupported", (long)D);
   VJ_CHECK_ARG(ws_bytes >= vj_layernorm_bwd_ws_bytes(D), "vj_layernorm_bwd: workspace too small");
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(LN_BWD_BLOCKS), dim3(256), 0, stream, (const bf16_t*)dy_bf16,
-                     (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws,
-                     rows, (int)D);
+  int64_t nb = cdiv64(rows, 16);  // >= 16 rows per workgroup so the column partials amortise
+  if (nb > LN_BWD_MAX_BLOCKS) nb = LN_BWD_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+#define VJ_LNB(NCHV)                                                                                                \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NCHV>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16,   \
+                     (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws, \
+                     rows, (int)D)
+  if (D <= 512) VJ_LNB(1);
+  else if (D <= 1024) VJ_LNB(2);
+  else if (D <= 1536) VJ_LNB(3);
+  else VJ_LNB(4);
+#undef VJ_LNB
   VJ_LAUNCH_CHECK("vj_layernorm_bwd");
-  // partial layout [blk][2][D] -> view as P=LN_BWD_BLOCKS rows of 2D columns; reduce halves separately
-  int rc = vj_reduce_partials_strided((const float*)ws, dgamma, LN_BWD_BLOCKS, D, 2 * D, alpha, beta_acc, stream);
+  int rc = vj_reduce_partials_strided((const float*)ws, dgamma, nb, D, 2 * D, alpha, beta_acc, stream);
   if (rc) return rc;
-  return vj_reduce_partials_strided((const float*)ws + D, dbeta, LN_BWD_BLOCKS, D, 2 * D, alpha, beta_acc, stream);
-}
-
-__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* __restrict__ part,
-                                                                      float* __restrict__ out, int64_t P, int64_t N,
-                                                                      int64_t stride, float alpha, float beta) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int64_t p = 0; p < P; p++) s += part[p * stride + n];
-  s *= alpha;
-  if (beta != 0.f) s += beta * out[n];
-  out[n] = s;
-}
-
-int vj_reduce_partials_strided(const float* part, float* out, int64_t P, int64_t N, int64_t stride, float alpha,
-                               float beta, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, stream, part, out,
-                     P, N, stride, alpha, beta);
-  VJ_LAUNCH_CHECK("vj_reduce_partials_strided");
-  return 0;
+  return vj_reduce_partials_strided((const float*)ws + D, dbeta, nb, D, 2 * D, alpha, beta_acc, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -241,7 +241,8 @@ extern "C" int vj_pred_assemble_fwd(const void* e_bf16, const float* mask_token,
 // Feeds the K-contiguous ("NT") MFMA GEMM with the wgrad operands dY^T and X^T.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                             int64_t M, int64_t N, int64_t ld_in, int64_t Mpad) {
+                                                             int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,
+                                                             float* __restrict__ part) {
   __shared__ bf16_t tile[64][66];
   const int64_t m0 = (int64_t)blockIdx.x * 64, n0 = (int64_t)blockIdx.y * 64;
   const int t = threadIdx.x;
@@ -258,6 +259,12 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
   }
   __syncthreads();
+  if (part != nullptr && t < 64 && n0 + t < N) {  // fused bias-gradient partial: column sums of this 64-row tile
+    float sum = 0.f;
+#pragma unroll 16
+    for (int r = 0; r < 64; r++) sum += bf2f(tile[r][t]);
+    part[(int64_t)blockIdx.x * N + n0 + t] = sum;
+  }
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const int q = t + it * 256;
@@ -280,9 +287,29 @@ extern "C" int vj_transpose_bf16(const void* in, void* out, int64_t M, int64_t N
   if (N == 0 || Mpad == 0) return 0;
   dim3 grid((unsigned)cdiv64(Mpad, 64), (unsigned)cdiv64(N, 64));
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, M, N, ld_in,
-                     Mpad);
+                     Mpad, (float*)nullptr);
   VJ_LAUNCH_CHECK("vj_transpose_bf16");
   return 0;
+}
+
+extern "C" int vj_reduce_partials(const float* part, float* out, int64_t P, int64_t N, float alpha, float beta,
+                                  hipStream_t stream);
+
+// transpose + bias gradient in one pass over dY: out = in^T (zero padded), colsum[n] = alpha*sum_m in[m][n] + beta*colsum[n]
+extern "C" int64_t vj_transpose_colsum_ws_bytes(int64_t M, int64_t N) { return cdiv64(((M + 63) / 64) * 64, 64) * N * 4; }
+
+extern "C" int vj_transpose_colsum_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,
+                                        float* colsum, float alpha, float beta, void* ws, int64_t ws_bytes,
+                                        hipStream_t stream) {
+  VJ_CHECK_ARG(N % 8 == 0 && ld_in % 8 == 0 && Mpad % 8 == 0 && Mpad >= M, "vj_transpose_colsum_bf16: bad dims");
+  const int64_t mt = cdiv64(Mpad, 64);
+  VJ_CHECK_ARG(ws_bytes >= mt * N * 4, "vj_transpose_colsum_bf16: workspace too small");
+  if (N == 0 || Mpad == 0) return 0;
+  dim3 grid((unsigned)mt, (unsigned)cdiv64(N, 64));
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, (bf16_t*)out, M, N, ld_in,
+                     Mpad, (float*)ws);
+  VJ_LAUNCH_CHECK("vj_transpose_colsum_bf16");
+  return vj_reduce_partials((const float*)ws, colsum, mt, N, alpha, beta, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,25 +353,44 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   }
 }
 
-// out[n] = alpha * sum_p part[p][n] + (beta != 0 ? beta * out[n] : 0)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int64_t P, int64_t N, float alpha, float beta) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+// out[n] = alpha * sum_p part[p*stride + n] + (beta != 0 ? beta * out[n] : 0)
+// one workgroup per 64 columns, 8 partial-lanes of 64 threads each (coalesced 256-B row reads, 8 in flight),
+// then a fixed-order LDS combine -> deterministic.
+__global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int64_t P, int64_t N, int64_t stride, float alpha,
+                                                              float beta) {
+  __shared__ float red[8][64];
+  const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int64_t p = 0; p < P; p++) s += part[p * N + n];
-  s *= alpha;
-  if (beta != 0.f) s += beta * out[n];
-  out[n] = s;
+  if (n < N) {
+#pragma unroll 8
+    for (int64_t p = pl; p < P; p += 8) s += part[p * stride + n];
+  }
+  red[pl][c] = s;
+  __syncthreads();
+  if (pl == 0 && n < N) {
+    float t = red[0][c];
+#pragma unroll
+    for (int i = 1; i < 8; i++) t += red[i][c];
+    t *= alpha;
+    if (beta != 0.f) t += beta * out[n];
+    out[n] = t;
+  }
+}
+
+int vj_reduce_partials_strided(const float* part, float* out, int64_t P, int64_t N, int64_t stride, float alpha,
+                               float beta, hipStream_t stream) {
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(512), 0, stream, part, out, P, N,
+                     stride, alpha, beta);
+  VJ_LAUNCH_CHECK("vj_reduce_partials");
+  return 0;
 }
 
 extern "C" int vj_reduce_partials(const float* part, float* out, int64_t P, int64_t N, float alpha, float beta,
                                   hipStream_t stream) {
-  if (N == 0) return 0;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, stream, part, out, P, N,
-                     alpha, beta);
-  VJ_LAUNCH_CHECK("vj_reduce_partials");
-  return 0;
+  return vj_reduce_partials_strided(part, out, P, N, N, alpha, beta, stream);
 }
 
 extern "C" int64_t vj_colsum_ws_bytes(int64_t N) { return (int64_t)VJ_COLSUM_PARTS * N * 4; }

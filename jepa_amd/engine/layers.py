@@ -63,11 +63,9 @@ def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
 
 def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None):
     """dW (fp32, into lw.gw) = alpha * dy^T x_in ; db = alpha * colsum(dy) ; returns dx = dy W (bf16)."""
-    dyT = ops.transpose(dy)
+    dyT = ops.transpose_colsum(dy, lw.gb, alpha=alpha) if lw.gb is not None else ops.transpose(dy)
     xT = ops.transpose(x_in)
-    ops.gemm_nt(dyT, xT, out=lw.gw, epilogue=ops.EPI_F32, alpha=alpha, M=lw.gw.shape[0], K=dyT.shape[1])
-    if lw.gb is not None:
-        ops.colsum(dy, lw.gb, alpha=alpha)
+    ops.gemm_wgrad(dyT, xT, lw.gw, alpha=alpha)
     if not need_dx:
         return None
     if dgelu_aux is not None:

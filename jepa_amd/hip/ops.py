@@ -180,6 +180,39 @@ def gemm_nt(A, B, out=None, bias=None, residual=None, aux_in=None, aux_out=None,
     return out
 
 
+WGRAD_WS_BYTES = 96 << 20
+
+
+def gemm_wgrad(dyT, xT, out, alpha=1.0, beta=0.0, flags=None, stream=None):
+    """out[N_out, K_in] (fp32) = alpha * dyT[N_out, Tp] @ xT[K_in, Tp]^T + beta*out, split-K over the tokens."""
+    lib = load_library()
+    M, K = dyT.shape
+    N = xT.shape[0]
+    ws = Scratch.get(WGRAD_WS_BYTES, dyT.device, "wgrad")
+    _ev = _timed("gemm_nt", 2.0 * M * N * K)
+    check(lib.vj_gemm_bf16_nt_splitk(_ptr(dyT), dyT.stride(0), _ptr(xT), xT.stride(0), _ptr(out), out.stride(0), M, N,
+                                     K, alpha, beta, GEMM_FLAGS if flags is None else flags, _ptr(ws), WGRAD_WS_BYTES,
+                                     _stream(stream)), "vj_gemm_bf16_nt_splitk")
+    if _ev is not None:
+        _ev.record()
+    return out
+
+
+def transpose_colsum(x, colsum_out, alpha=1.0, accumulate=False, stream=None):
+    """x [M,N] bf16 -> x^T [N, pad64(M)] and colsum_out[n] = alpha*sum_m x[m,n] (+ old) in one pass."""
+    lib = load_library()
+    _req(x, BF16, "x")
+    M, N = x.shape
+    Mp = pad64(M)
+    out = torch.empty((N, Mp), dtype=BF16, device=x.device)
+    nws = lib.vj_transpose_colsum_ws_bytes(M, N)
+    ws = Scratch.get(nws, x.device, "tcolsum")
+    check(lib.vj_transpose_colsum_bf16(_ptr(x), _ptr(out), M, N, x.stride(0), Mp, _ptr(colsum_out), alpha,
+                                       1.0 if accumulate else 0.0, _ptr(ws), nws, _stream(stream)),
+          "vj_transpose_colsum_bf16")
+    return out
+
+
 def pad64(m):
     return (m + 63) // 64 * 64
 

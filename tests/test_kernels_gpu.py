@@ -361,3 +361,23 @@ def test_probe_tr16_dump(ops):
                 f.write(f"  lane {lane:2d}: {r}\n")
     expect = [[(l & 15) + 16 * j + 64 * (l >> 4) for j in range(4)] for l in range(64)]
     print("tr16 mapping matches guide formula:", res[8] == expect)
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 11392), (384, 384, 27900), (3072, 1024, 473), (96, 288, 66)])
+def test_gemm_wgrad_splitk_and_fused_colsum(ops, M, N, K):
+    """Split-K wgrad (deterministic slice reduction) + bias gradient fused into the dY transpose."""
+    g = torch.Generator().manual_seed(14)
+    dY = bf(torch.randn(K, M, generator=g)).to(DEV)
+    X = bf(torch.randn(K, N, generator=g)).to(DEV)
+    db = torch.full((M,), 2.0, device=DEV)
+    dYt = ops.transpose_colsum(dY, db, alpha=0.5, accumulate=True)
+    assert torch.equal(dYt[:, :K], dY.t()) and torch.count_nonzero(dYt[:, K:]) == 0
+    assert torch.allclose(db, 0.5 * dY.float().sum(0) + 2.0, rtol=1e-5, atol=2e-3)
+    Xt = ops.transpose(X)
+    out = torch.full((M, N), 1.0, device=DEV)
+    ops.gemm_wgrad(dYt, Xt, out, alpha=0.25, beta=3.0)
+    ref = 0.25 * (dY.float().t() @ X.float()) + 3.0
+    assert rel_l2(out, ref) < 1e-5, rel_l2(out, ref)
+    out2 = torch.full((M, N), 1.0, device=DEV)
+    ops.gemm_wgrad(dYt, Xt, out2, alpha=0.25, beta=3.0)
+    assert torch.equal(out, out2)  # deterministic
