@@ -11,15 +11,15 @@
 // are lane-local (query = lane&15), (ii) the exponentiated scores feed the next MFMA straight from the
 // accumulator registers (the contraction index is permuted identically on both operands, so no cross-lane
 // movement), and (iii) every lane owns 4 consecutive head-dim columns of the result (8-byte stores).
-// K/V (or Q/dO) tiles of 64 rows are staged through LDS in two images: row-major with a 16-byte XOR swizzle
-// (ds_read_b128 fragments) and transposed [hd][64+8] (ds_read_b64 fragments for the operand whose contraction
-// index is the token).  The next tile's global loads are issued before the current tile's MFMAs.
+// K/V (or Q/dO) tiles of 64 rows are staged through LDS ONCE, row-major with a 16-byte XOR swizzle: operands that
+// contract over head-dim are read as ds_read_b128 fragments, operands that contract over the token index are read
+// with the gfx950 transpose read ds_read_b64_tr_b16 from the same image (no transposed copy, no scatter stores).
+// The next tile's global loads are issued before the current tile's MFMAs.
 //
 // Softmax is computed in base 2: s2 = (q.k) * scale * log2(e); lse2 = max2 + log2(sum) is what the forward
 // saves for the backward (an internal format, produced and consumed only here).
 #include "common.hpp"
 
-#define VP 72  // transposed-image row pitch (elements): 64 tokens + 8 pad, 144 B keeps ds_read_b64 8-byte aligned
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
@@ -64,49 +64,34 @@ struct RowTile {
   }
 };
 
-// ---- transposed image: [HDP][VP], token index contiguous ----------------------------------------------------
+// ---- transposed fragments straight from the row-major image: ds_read_b64_tr_b16 ------------------------------
+// MFMA operand whose contraction index is the TOKEN (V in P.V, Q/dO in dK/dV, K in dQ): lane (g = lane>>4,
+// i = lane&15) needs column d0+i of the 8 tokens {t0+4g+0..3, t0+16+4g+0..3}.  The gfx950 transpose read delivers
+// exactly that from row-major data: within a 16-lane group, lane 4j+q supplies the address of the 8-byte chunk
+// (row j, columns 4q..4q+3) and lane i receives column i of the four rows (mapping verified on hardware by
+// tests/test_kernels_gpu.py::test_probe_tr16_dump).  Two reads (rows t0.. and t0+16..) fill the 8 k-slots.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 template <int HDP>
-struct ColTile {
-  static constexpr int CHP = HDP / 8;
-  static constexpr int NIT = (32 * CHP + 255) / 256;
-  static constexpr int BYTES = HDP * VP * 2;
-  static __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int64_t rs, int r0, int nrows, int hd,
-                                              int tid, u32x4_t (*regs)[2]) {
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int item = tid + it * 256;
-      const int kp = item & 31, ch = item >> 5;
-      u32x4_t v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
-      if (item < 32 * CHP && ch * 8 < hd) {
-        const int ra = r0 + 2 * kp;
-        if (ra < nrows) v0 = *(const u32x4_t*)(base + (int64_t)ra * rs + ch * 8);
-        if (ra + 1 < nrows) v1 = *(const u32x4_t*)(base + (int64_t)(ra + 1) * rs + ch * 8);
-      }
-      regs[it][0] = v0;
-      regs[it][1] = v1;
-    }
+struct TrFrag {
+  int row_off;   // byte offset of this lane's source row (t0 = 0)
+  int kx;        // row & 7 (swizzle key of that row; identical for row+16)
+  int qlo, qhi;  // (q & 1) * 8 and q >> 1 for this lane's 4-column chunk
+  __device__ __forceinline__ TrFrag(int lane) {
+    const int g = lane >> 4, j = (lane & 15) >> 2, q = lane & 3;
+    const int row = 4 * g + j;
+    row_off = row * (HDP * 2);
+    kx = rm_swz<HDP>(row);
+    qlo = (q & 1) * 8;
+    qhi = q >> 1;
   }
-  static __device__ __forceinline__ void store(char* lds, int tid, const u32x4_t (*regs)[2]) {
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int item = tid + it * 256;
-      const int kp = item & 31, ch = item >> 5;
-      if (item < 32 * CHP) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const uint32_t a = regs[it][0][e >> 1], b = regs[it][1][e >> 1];
-          const uint32_t lo = (e & 1) ? (a >> 16) : (a & 0xffffu);
-          const uint32_t hi = (e & 1) ? (b & 0xffff0000u) : (b << 16);
-          *(uint32_t*)(lds + ((ch * 8 + e) * VP + 2 * kp) * 2) = lo | hi;
-        }
-      }
-    }
-  }
-  // MFMA fragment for the 32-token chunk c of column d: tokens {c*32+4g..+3, c*32+16+4g..+3}
-  static __device__ __forceinline__ bf16x8_t frag(const char* lds, int d, int c, int g) {
-    const u32x2_t lo = *(const u32x2_t*)(lds + (d * VP + c * 32 + 4 * g) * 2);
-    const u32x2_t hi = *(const u32x2_t*)(lds + (d * VP + c * 32 + 16 + 4 * g) * 2);
-    u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
+  // tokens t0 + {4g..4g+3, 16+4g..16+4g+3} (t0 multiple of 32), columns d0 .. d0+15 (d0 multiple of 16)
+  __device__ __forceinline__ bf16x8_t load(const char* lds, int t0, int d0) const {
+    const char* p0 = lds + t0 * (HDP * 2) + row_off + ((((d0 >> 3) + qhi) ^ kx) * 16) + qlo;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * HDP * 2));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, w);
   }
 };
@@ -129,9 +114,10 @@ template <int HDP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                        float* __restrict__ lse2, int B, int S, int H, int hd,
                                                        float sc, int nqb) {
-  __shared__ __attribute__((aligned(16))) char smem[RowTile<HDP>::BYTES + ColTile<HDP>::BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES];
   char* k_lds = smem;
-  char* vt_lds = smem + RowTile<HDP>::BYTES;
+  char* v_lds = smem + RowTile<HDP>::BYTES;
+  const TrFrag<HDP> trf(threadIdx.x & 63);
   constexpr int KS = HDP / 32, DT = HDP / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -160,21 +146,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int dt = 0; dt < DT; dt++) oacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
 
-  u32x4_t kreg[RowTile<HDP>::NIT];
-  u32x4_t vreg[ColTile<HDP>::NIT][2];
+  u32x4_t kreg[RowTile<HDP>::NIT], vreg[RowTile<HDP>::NIT];
   const int nt = (S + 63) / 64;
   RowTile<HDP>::load(kbase, rs, 0, S, hd, tid, kreg);
-  ColTile<HDP>::load(vbase, rs, 0, S, hd, tid, vreg);
+  RowTile<HDP>::load(vbase, rs, 0, S, hd, tid, vreg);
 
   for (int t = 0; t < nt; t++) {
     const int k0 = t * 64;
     __syncthreads();  // every wave is done with the previous tile's LDS image
     RowTile<HDP>::store(k_lds, tid, kreg);
-    ColTile<HDP>::store(vt_lds, tid, vreg);
+    RowTile<HDP>::store(v_lds, tid, vreg);
     __syncthreads();
     if (t + 1 < nt) {  // next tile's loads fly under this tile's MFMAs
       RowTile<HDP>::load(kbase, rs, k0 + 64, S, hd, tid, kreg);
-      ColTile<HDP>::load(vbase, rs, k0 + 64, S, hd, tid, vreg);
+      RowTile<HDP>::load(vbase, rs, k0 + 64, S, hd, tid, vreg);
     }
     // ---- S^T = K Q^T : sacc[qt][kt] holds S^T[key = kt*16 + 4g + r][q = li] ----
     f32x4_t sacc[2][4];
@@ -240,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int dt = 0; dt < DT; dt++) {
-        const bf16x8_t vf = ColTile<HDP>::frag(vt_lds, dt * 16 + li, c, g);
+        const bf16x8_t vf = trf.load(v_lds, c * 32, dt * 16);
 #pragma unroll
         for (int qt = 0; qt < 2; qt++)
           oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
@@ -307,13 +292,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
                                                             const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
                                                             float sc, float scale, int nkb) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES + 2 * ColTile<HDP>::BYTES + 2 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES + 2 * 64 * 4];
   char* q_lds = smem;
   char* do_lds = smem + RowTile<HDP>::BYTES;
-  char* qt_lds = smem + 2 * RowTile<HDP>::BYTES;
-  char* dot_lds = qt_lds + ColTile<HDP>::BYTES;
-  float* lse_s = (float*)(dot_lds + ColTile<HDP>::BYTES);
+  float* lse_s = (float*)(smem + 2 * RowTile<HDP>::BYTES);
   float* dl_s = lse_s + 64;
+  const TrFrag<HDP> trf(threadIdx.x & 63);
   constexpr int KS = HDP / 32, DT = HDP / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -346,14 +330,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
   }
 
   u32x4_t qreg[RowTile<HDP>::NIT], doreg[RowTile<HDP>::NIT];
-  u32x4_t qtreg[ColTile<HDP>::NIT][2], dotreg[ColTile<HDP>::NIT][2];
   float lse_r = 0.f, dl_r = 0.f;
   const int nt = (S + 63) / 64;
   auto load_tile = [&](int r0) {
     RowTile<HDP>::load(qbase, rs, r0, S, hd, tid, qreg);
     RowTile<HDP>::load(dobase, os, r0, S, hd, tid, doreg);
-    ColTile<HDP>::load(qbase, rs, r0, S, hd, tid, qtreg);
-    ColTile<HDP>::load(dobase, os, r0, S, hd, tid, dotreg);
     if (tid < 64) {
       const int q = r0 + tid;
       lse_r = q < S ? lse_b[q] : INFINITY;  // +inf -> P = 0 for padded query rows
@@ -366,8 +347,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
     __syncthreads();
     RowTile<HDP>::store(q_lds, tid, qreg);
     RowTile<HDP>::store(do_lds, tid, doreg);
-    ColTile<HDP>::store(qt_lds, tid, qtreg);
-    ColTile<HDP>::store(dot_lds, tid, dotreg);
     if (tid < 64) {
       lse_s[tid] = lse_r;
       dl_s[tid] = dl_r;
@@ -409,8 +388,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
       const bf16x8_t dfr = __builtin_bit_cast(bf16x8_t, dw);
 #pragma unroll
       for (int dt = 0; dt < DT; dt++) {
-        const bf16x8_t dot_f = ColTile<HDP>::frag(dot_lds, dt * 16 + li, c, g);
-        const bf16x8_t qt_f = ColTile<HDP>::frag(qt_lds, dt * 16 + li, c, g);
+        const bf16x8_t dot_f = trf.load(do_lds, c * 32, dt * 16);
+        const bf16x8_t qt_f = trf.load(q_lds, c * 32, dt * 16);
         dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr, dvacc[dt], 0, 0, 0);
         dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dfr, dkacc[dt], 0, 0, 0);
       }
@@ -448,10 +427,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
                                                           float sc, float scale, int nqb) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES + ColTile<HDP>::BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES];
   char* k_lds = smem;
   char* v_lds = smem + RowTile<HDP>::BYTES;
-  char* kt_lds = smem + 2 * RowTile<HDP>::BYTES;
+  const TrFrag<HDP> trf(threadIdx.x & 63);
   constexpr int KS = HDP / 32, DT = HDP / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -487,23 +466,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int dt = 0; dt < DT; dt++) dqacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   u32x4_t kreg[RowTile<HDP>::NIT], vreg[RowTile<HDP>::NIT];
-  u32x4_t ktreg[ColTile<HDP>::NIT][2];
   const int nt = (S + 63) / 64;
   RowTile<HDP>::load(kbase, rs, 0, S, hd, tid, kreg);
   RowTile<HDP>::load(vbase, rs, 0, S, hd, tid, vreg);
-  ColTile<HDP>::load(kbase, rs, 0, S, hd, tid, ktreg);
 
   for (int t = 0; t < nt; t++) {
     const int k0 = t * 64;
     __syncthreads();
     RowTile<HDP>::store(k_lds, tid, kreg);
     RowTile<HDP>::store(v_lds, tid, vreg);
-    ColTile<HDP>::store(kt_lds, tid, ktreg);
     __syncthreads();
     if (t + 1 < nt) {
       RowTile<HDP>::load(kbase, rs, k0 + 64, S, hd, tid, kreg);
       RowTile<HDP>::load(vbase, rs, k0 + 64, S, hd, tid, vreg);
-      ColTile<HDP>::load(kbase, rs, k0 + 64, S, hd, tid, ktreg);
     }
     f32x4_t sacc[2][4], dpacc[2][4];
 #pragma unroll
@@ -549,7 +524,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int dt = 0; dt < DT; dt++) {
-        const bf16x8_t ktf = ColTile<HDP>::frag(kt_lds, dt * 16 + li, c, g);
+        const bf16x8_t ktf = trf.load(k_lds, c * 32, dt * 16);
 #pragma unroll
         for (int qt = 0; qt < 2; qt++)
           dqacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt][c], dqacc[qt][dt], 0, 0, 0);

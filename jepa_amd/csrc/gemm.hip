@@ -33,8 +33,9 @@ struct GemmArgs {
   float* ws;
 };
 
-#define BM 128
-#define BN 128
+// tile configurations: <BM, BN, WM, WN> = block tile and wave grid; each wave owns (BM/WM) x (BN/WN)
+//   128x128, 2x2 waves (64x64 per wave)  : 64 KB LDS, 2 workgroups / CU -- small / skinny problems
+//   256x256, 2x4 waves (128x64 per wave) : 128 KB LDS, 1 workgroup / CU, 2 waves / SIMD -- 2x the L2->LDS reuse
 
 template <int BK>
 __device__ __forceinline__ int swz_of(int row) {
@@ -42,21 +43,21 @@ __device__ __forceinline__ int swz_of(int row) {
 }
 
 // ---- staging: one 128 x BK bf16 operand tile -> LDS (lane-linear image, source-side swizzle) ----
-template <int BK, bool GLDS>
+template <int BK, bool GLDS, int ROWS, int NT>
 __device__ __forceinline__ void stage_issue(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t rows,
                                             int64_t k0, char* lds_tile, int tid, int wave_u, u32x4_t* regs) {
   constexpr int CPR = BK / 8;                  // 16-byte chunks per tile row
-  constexpr int NIT = (128 * CPR) / 256;       // chunks per thread
+  constexpr int NIT = (ROWS * CPR) / NT;       // chunks per thread
 #pragma unroll
   for (int j = 0; j < NIT; j++) {
-    const int q = j * 256 + tid;
+    const int q = j * NT + tid;
     const int row = q / CPR, cpos = q % CPR;
     const int c = cpos ^ swz_of<BK>(row);
     int64_t gr = row0 + row;
     gr = gr < rows ? gr : rows - 1;            // clamp: tail rows are never stored
     const bf16_t* src = G + gr * ld + k0 + c * 8;
     if constexpr (GLDS) {
-      char* dst = lds_tile + (j * 256 + wave_u * 64) * 16;  // wave-uniform base; HW adds lane*16
+      char* dst = lds_tile + (j * NT + wave_u * 64) * 16;  // wave-uniform base; HW adds lane*16
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     } else {
@@ -65,26 +66,28 @@ __device__ __forceinline__ void stage_issue(const bf16_t* __restrict__ G, int64_
   }
 }
 
-template <int BK>
+template <int BK, int ROWS, int NT>
 __device__ __forceinline__ void stage_commit(char* lds_tile, int tid, const u32x4_t* regs) {
   constexpr int CPR = BK / 8;
-  constexpr int NIT = (128 * CPR) / 256;
+  constexpr int NIT = (ROWS * CPR) / NT;
 #pragma unroll
   for (int j = 0; j < NIT; j++) {
-    const int q = j * 256 + tid;
+    const int q = j * NT + tid;
     *(u32x4_t*)(lds_tile + q * 16) = regs[j];
   }
 }
 
-template <int BK, int EPI, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+template <int BK, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TILE_BYTES = 128 * BK * 2;
+  constexpr int NT = WM * WN * 64;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int CPR = BK / 8;
-  constexpr int NIT = (128 * CPR) / 256;
+  constexpr int NIT_A = (BM * CPR) / NT, NIT_B = (BN * CPR) / NT;
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;   // 16x16 MFMA tiles per wave
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave_u >> 1, wn = wave_u & 1;
+  const int wm = wave_u / WN, wn = wave_u % WN;
 
   // ---- XCD-aware, grouped tile mapping (bijective for any grid size) ----
   const int ntile = p.tiles_m * p.tiles_n;
@@ -102,79 +105,83 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   const int tm = first_m + in_g % gsz, tn = in_g / gsz;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[FM][FN];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < FM; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int nk_all = (int)(p.K / BK);
   const int kt0 = slice * p.ktiles_per;
   const int kt1 = (kt0 + p.ktiles_per) < nk_all ? (kt0 + p.ktiles_per) : nk_all;
-  u32x4_t ra[NIT], rb[NIT];
+  u32x4_t ra[NIT_A], rb[NIT_B];
 
   // fragment read offsets (bytes inside a tile), constant across K-tiles
   const int frow = lane & 15, fg = lane >> 4;
-  int a_off[4][BK / 32], b_off[4][BK / 32];
+  int a_off[FM][BK / 32], b_off[FN][BK / 32];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int ks = 0; ks < BK / 32; ks++) {
+    const int c = ks * 4 + fg;
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ks++) {
-      const int ra_ = wm * 64 + i * 16 + frow, rb_ = wn * 64 + i * 16 + frow;
-      const int c = ks * 4 + fg;
-      a_off[i][ks] = ra_ * (BK * 2) + ((c ^ swz_of<BK>(ra_)) * 16);
-      b_off[i][ks] = rb_ * (BK * 2) + ((c ^ swz_of<BK>(rb_)) * 16);
+    for (int i = 0; i < FM; i++) {
+      const int r_ = wm * (FM * 16) + i * 16 + frow;
+      a_off[i][ks] = r_ * (BK * 2) + ((c ^ swz_of<BK>(r_)) * 16);
     }
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      const int r_ = wn * (FN * 16) + j * 16 + frow;
+      b_off[j][ks] = r_ * (BK * 2) + ((c ^ swz_of<BK>(r_)) * 16);
+    }
+  }
 
   // prologue: stage this slice's first K-tile into buffer 0
   if (kt0 < kt1) {
-    stage_issue<BK, GLDS>(p.A, p.lda, m0, p.M, (int64_t)kt0 * BK, smem, tid, wave_u, ra);
-    stage_issue<BK, GLDS>(p.B, p.ldb, n0, p.N, (int64_t)kt0 * BK, smem + TILE_BYTES, tid, wave_u, rb);
+    stage_issue<BK, GLDS, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)kt0 * BK, smem, tid, wave_u, ra);
+    stage_issue<BK, GLDS, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)kt0 * BK, smem + A_BYTES, tid, wave_u, rb);
     if constexpr (!GLDS) {
-      stage_commit<BK>(smem, tid, ra);
-      stage_commit<BK>(smem + TILE_BYTES, tid, rb);
+      stage_commit<BK, BM, NT>(smem, tid, ra);
+      stage_commit<BK, BN, NT>(smem + A_BYTES, tid, rb);
     }
   }
 
   for (int kt = kt0; kt < kt1; kt++) {
-    char* cur = smem + ((kt - kt0) & 1) * (2 * TILE_BYTES);
-    char* nxt = smem + ((kt - kt0 + 1) & 1) * (2 * TILE_BYTES);
+    char* cur = smem + ((kt - kt0) & 1) * STAGE_BYTES;
+    char* nxt = smem + ((kt - kt0 + 1) & 1) * STAGE_BYTES;
     if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt is in LDS for every wave; every wave is done reading tile kt-1
     if (kt + 1 < kt1) {
-      stage_issue<BK, GLDS>(p.A, p.lda, m0, p.M, (int64_t)(kt + 1) * BK, nxt, tid, wave_u, ra);
-      stage_issue<BK, GLDS>(p.B, p.ldb, n0, p.N, (int64_t)(kt + 1) * BK, nxt + TILE_BYTES, tid, wave_u, rb);
+      stage_issue<BK, GLDS, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)(kt + 1) * BK, nxt, tid, wave_u, ra);
+      stage_issue<BK, GLDS, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)(kt + 1) * BK, nxt + A_BYTES, tid, wave_u, rb);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ks++) {
-      bf16x8_t af[4], bfr[4];
+      bf16x8_t af[FM], bfr[FN];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        af[i] = *(const bf16x8_t*)(cur + a_off[i][ks]);
-        bfr[i] = *(const bf16x8_t*)(cur + TILE_BYTES + b_off[i][ks]);
-      }
+      for (int j = 0; j < FN; j++) bfr[j] = *(const bf16x8_t*)(cur + A_BYTES + b_off[j][ks]);
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < FM; i++) af[i] = *(const bf16x8_t*)(cur + a_off[i][ks]);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+      for (int i = 0; i < FM; i++)
+#pragma unroll
+        for (int j = 0; j < FN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if constexpr (!GLDS) {
       if (kt + 1 < kt1) {  // other buffer: nobody reads it until the next barrier
-        stage_commit<BK>(nxt, tid, ra);
-        stage_commit<BK>(nxt + TILE_BYTES, tid, rb);
+        stage_commit<BK, BM, NT>(nxt, tid, ra);
+        stage_commit<BK, BN, NT>(nxt + A_BYTES, tid, rb);
       }
     }
   }
 
   // ---- epilogue: lane owns rows m = .. + (lane&15), columns n = .. + 4*(lane>>4) + {0,1,2,3} ----
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int64_t m = m0 + wm * 64 + i * 16 + frow;
+  for (int i = 0; i < FM; i++) {
+    const int64_t m = m0 + wm * (FM * 16) + i * 16 + frow;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int64_t n = n0 + wn * 64 + j * 16 + fg * 4;
+    for (int j = 0; j < FN; j++) {
+      const int64_t n = n0 + wn * (FN * 16) + j * 16 + fg * 4;
       if (n >= p.N) continue;  // N % 4 == 0 is enforced by the host wrapper
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if constexpr (EPI == EPI_F32) {
@@ -262,42 +269,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
   }
 }
 
-template <int BK, int EPI, bool GLDS>
-static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
-  constexpr int smem = 2 * 2 * 128 * BK * 2;
+template <int BK, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
+static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  constexpr int smem = 2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, EPI, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, EPI, GLDS, BM, BN, WM, WN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   GemmArgs b = a;
+  b.tiles_m = (int)cdiv64(a.M, BM);
+  b.tiles_n = (int)cdiv64(a.N, BN);
+  b.splitk = 1;
+  b.ws = nullptr;
   const int nk = (int)(a.K / BK);
-  if (b.splitk > nk) b.splitk = nk;
-  if (b.splitk < 1) b.splitk = 1;
+  if (EPI == EPI_F32 && ws != nullptr) {
+    // wgrad: fill the chip (>= 2 waves of workgroups); each slice keeps >= 8 K-tiles of work
+    const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
+    int64_t s = cdiv64(512, tiles);
+    const int64_t max_by_k = nk / 8 > 0 ? nk / 8 : 1;
+    if (s > max_by_k) s = max_by_k;
+    while (s > 1 && s * a.M * a.N * 4 > ws_bytes) s--;
+    b.splitk = (int)s;
+    b.ws = (float*)ws;
+  }
   b.ktiles_per = (nk + b.splitk - 1) / b.splitk;
   b.splitk = (nk + b.ktiles_per - 1) / b.ktiles_per;  // no empty slices
-  const int nblk = a.tiles_m * a.tiles_n * b.splitk;
-  hipLaunchKernelGGL((gemm_nt_kernel<BK, EPI, GLDS>), dim3(nblk), dim3(256), smem, stream, b);
+  const int nblk = b.tiles_m * b.tiles_n * b.splitk;
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, EPI, GLDS, BM, BN, WM, WN>), dim3(nblk), dim3(WM * WN * 64), smem, stream, b);
   VJ_LAUNCH_CHECK("vj_gemm_bf16_nt");
   if (b.splitk > 1) {
     const int64_t n4 = a.M * a.N / 4;
     int64_t g = cdiv64(n4, 256);
     if (g > 256 * 8) g = 256 * 8;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float4*)a.ws,
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float4*)b.ws,
                        (float*)a.C, a.M, a.N, a.ldc, b.splitk, a.alpha, a.beta);
     VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(splitk reduce)");
   }
   return 0;
 }
 
+// flags: bit0 = register-staged operands (A/B testing); bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256)
 template <int EPI>
-static int dispatch_gemm(const GemmArgs& a, int flags, hipStream_t stream) {
+static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   const bool reg_staged = (flags & 1) != 0;
-  if (a.K % 64 == 0) return reg_staged ? launch_gemm<64, EPI, false>(a, stream) : launch_gemm<64, EPI, true>(a, stream);
-  return reg_staged ? launch_gemm<32, EPI, false>(a, stream) : launch_gemm<32, EPI, true>(a, stream);
+  int cfg = (flags >> 4) & 3;
+  if (a.K % 64 != 0) cfg = 1;  // the K%32 fallback exists only for the small tile
+  if (cfg == 0) {
+    // 256x256 halves the L2->LDS traffic per flop but needs enough tiles to keep 256 CUs busy in whole waves
+    const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
+    cfg = (EPI != EPI_F32 && t256 >= 1024) ? 2 : 1;  // measured on the ViT-L step shapes (tools/gemm_bench.py)
+  }
+  if (cfg == 2) {
+    return reg_staged ? launch_gemm<64, EPI, false, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
+                      : launch_gemm<64, EPI, true, 256, 256, 2, 4>(a, ws, ws_bytes, stream);
+  }
+  if (a.K % 64 == 0)
+    return reg_staged ? launch_gemm<64, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream)
+                      : launch_gemm<64, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
+  return reg_staged ? launch_gemm<32, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream)
+                    : launch_gemm<32, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
 }
 
-// flags: bit0 = register-staged operand path instead of LDS-DMA (same numerics; for A/B testing)
 static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                       int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
                       void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags, void* ws,
@@ -320,23 +354,12 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.aux_in = (const bf16_t*)aux_in; a.aux_out = (bf16_t*)aux_out;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.alpha = alpha; a.beta = beta;
-  a.tiles_m = (int)cdiv64(M, BM); a.tiles_n = (int)cdiv64(N, BN);
-  a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
-  if (epilogue == EPI_F32 && ws != nullptr) {
-    // fill the chip: aim at >= 2 workgroups per CU; each slice keeps >= 8 K-tiles of work
-    const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
-    int64_t s = cdiv64(512, tiles);
-    const int64_t max_by_k = (K / 64) / 8 > 0 ? (K / 64) / 8 : 1;
-    if (s > max_by_k) s = max_by_k;
-    while (s > 1 && s * M * N * 4 > ws_bytes) s--;
-    a.splitk = (int)s;
-    a.ws = (float*)ws;
-  }
+  a.tiles_m = a.tiles_n = 0; a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
   switch (epilogue) {
-    case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, stream);
-    case EPI_GELU: return dispatch_gemm<EPI_GELU>(a, flags, stream);
-    case EPI_DGELU: return dispatch_gemm<EPI_DGELU>(a, flags, stream);
-    default: return dispatch_gemm<EPI_F32>(a, flags, stream);
+    case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, nullptr, 0, stream);
+    case EPI_GELU: return dispatch_gemm<EPI_GELU>(a, flags, nullptr, 0, stream);
+    case EPI_DGELU: return dispatch_gemm<EPI_DGELU>(a, flags, nullptr, 0, stream);
+    default: return dispatch_gemm<EPI_F32>(a, flags, ws, ws_bytes, stream);
   }
 }
 

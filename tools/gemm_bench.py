@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""GEMM micro-benchmark over the shapes of the ViT-L V-JEPA step: every tile configuration, random operands
+(never zeros: DVFS), HIP events on the launch stream.  python tools/gemm_bench.py [--reps 20]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jepa_amd.hip import ops  # noqa: E402
+
+SHAPES = [  # (tag, M, N, K, epilogue)
+    ("tgt qkv", 37632, 3072, 1024, 0), ("tgt proj", 37632, 1024, 1024, 0), ("tgt fc1", 37632, 4096, 1024, 1),
+    ("tgt fc2", 37632, 1024, 4096, 0), ("tgt patch", 37632, 1024, 1536, 0),
+    ("ctx qkv", 11392, 3072, 1024, 0), ("ctx proj", 11392, 1024, 1024, 0), ("ctx fc1", 11392, 4096, 1024, 1),
+    ("ctx fc2", 11392, 1024, 4096, 0), ("ctx dfc2", 11392, 4096, 1024, 2), ("ctx dqkv", 11392, 1024, 3072, 0),
+    ("prd qkv", 27848, 1152, 384, 0), ("prd proj", 27848, 384, 384, 0), ("prd fc1", 27848, 1536, 384, 1),
+    ("prd fc2", 27848, 384, 1536, 0), ("prd dqkv", 27848, 384, 1152, 0),
+    ("wg qkv", 3072, 1024, 11392, 3), ("wg proj", 1024, 1024, 11392, 3), ("wg fc1", 4096, 1024, 11392, 3),
+    ("wg fc2", 1024, 4096, 11392, 3), ("wg p.qkv", 1152, 384, 27904, 3), ("wg p.proj", 384, 384, 27904, 3),
+    ("wg p.fc1", 1536, 384, 27904, 3), ("wg p.fc2", 384, 1536, 27904, 3),
+    ("sq 4096", 4096, 4096, 4096, 0), ("sq 8192", 8192, 8192, 8192, 0),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--cfgs", default="1,2")
+    args = ap.parse_args()
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    cfgs = [int(c) for c in args.cfgs.split(",")]
+    print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " + " ".join(f"cfg{c:>2d}(TF/s)" for c in cfgs))
+    for tag, M, N, K, epi in SHAPES:
+        A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+        B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+        bias = torch.randn(N, device=dev, generator=g)
+        aux = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16) if epi in (1, 2) else None
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
+        res = []
+        for c in cfgs:
+            flags = c << 4
+
+            def run():
+                if epi == 3:
+                    ops.gemm_wgrad(A, B, out, flags=flags)
+                elif epi == 1:
+                    ops.gemm_nt(A, B, out=out, bias=bias, aux_out=aux, epilogue=1, flags=flags)
+                elif epi == 2:
+                    ops.gemm_nt(A, B, out=out, aux_in=aux, epilogue=2, flags=flags)
+                else:
+                    ops.gemm_nt(A, B, out=out, bias=bias, flags=flags)
+            for _ in range(3):
+                run()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(args.reps):
+                run()
+            e.record()
+            torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / args.reps
+            res.append(2.0 * M * N * K / ms / 1e9)
+        print(f"{tag:10s} {M:6d} {N:5d} {K:6d} {epi:3d} " + " ".join(f"{r:12.1f}" for r in res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
