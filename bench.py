@@ -229,11 +229,15 @@ def main():
 
     roof = None
     if not args.no_roofline_pass:
+        from jepa_amd.engine.layers import side_stream
+        side = side_stream(device)
+        side.enabled = False       # per-kernel durations are only meaningful when kernels run one at a time
         ops.KERNEL_TIMERS = {}
         n_inst = min(3, args.steps)
         for i in range(n_inst):
             run(args.warmup + i)
         sync()
+        side.enabled = True
         timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
         fam = {}
         for name, evs in timers.items():

@@ -37,9 +37,12 @@ struct GemmArgs {
 //   128x128, 2x2 waves (64x64 per wave)  : 64 KB LDS, 2 workgroups / CU -- small / skinny problems
 //   256x256, 2x4 waves (128x64 per wave) : 128 KB LDS, 1 workgroup / CU, 2 waves / SIMD -- 2x the L2->LDS reuse
 
+// 16-byte-chunk XOR swizzle of a tile row (rows are BK*2 bytes): makes every ds_read_b128 lane group of a fragment
+// read hit 16 distinct 16-byte slots of the 256-byte bank row.  BK=64 (8 chunks/row): chunk ^= row&7.
+// BK=32 (4 chunks/row, 4 rows per bank row): chunk ^= (4 - ((row>>2)&3)) & 3.
 template <int BK>
 __device__ __forceinline__ int swz_of(int row) {
-  return BK == 64 ? (row & 7) : 0;
+  return BK == 64 ? (row & 7) : ((4 - ((row >> 2) & 3)) & 3);
 }
 
 // ---- staging: one 128 x BK bf16 operand tile -> LDS (lane-linear image, source-side swizzle) ----
@@ -77,9 +80,24 @@ __device__ __forceinline__ void stage_commit(char* lds_tile, int tid, const u32x
   }
 }
 
-template <int BK, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// NS = LDS ring depth.  NS == 2 is the classic double buffer (stage t+1 while multiplying t, drain before the
+// barrier).  NS > 2 keeps NS-2 stages of LDS-DMA in flight ACROSS the per-K-tile barrier with a counted
+// s_waitcnt vmcnt (never 0 in steady state) and a raw s_barrier, which is what hides HBM/L2 latency when the
+// K loop is short (K = 1024 / 384 in this model).
+template <int BK, int NS, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(GLDS || NS == 2, "register staging supports only the double buffer");
   constexpr int NT = WM * WN * 64;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int CPR = BK / 8;
@@ -134,24 +152,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     }
   }
 
-  // prologue: stage this slice's first K-tile into buffer 0
-  if (kt0 < kt1) {
-    stage_issue<BK, GLDS, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)kt0 * BK, smem, tid, wave_u, ra);
-    stage_issue<BK, GLDS, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)kt0 * BK, smem + A_BYTES, tid, wave_u, rb);
-    if constexpr (!GLDS) {
-      stage_commit<BK, BM, NT>(smem, tid, ra);
-      stage_commit<BK, BN, NT>(smem + A_BYTES, tid, rb);
+  constexpr int LOADS = NIT_A + NIT_B;  // LDS-DMA instructions per thread per stage
+  const int nkt = kt1 - kt0;
+  // prologue: put the first NS-1 stages in flight
+#pragma unroll
+  for (int st = 0; st < NS - 1; st++) {
+    if (st < nkt) {
+      char* slot = smem + st * STAGE_BYTES;
+      stage_issue<BK, GLDS, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)(kt0 + st) * BK, slot, tid, wave_u, ra);
+      stage_issue<BK, GLDS, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)(kt0 + st) * BK, slot + A_BYTES, tid, wave_u, rb);
+      if constexpr (!GLDS) {
+        stage_commit<BK, BM, NT>(slot, tid, ra);
+        stage_commit<BK, BN, NT>(slot + A_BYTES, tid, rb);
+      }
     }
   }
 
-  for (int kt = kt0; kt < kt1; kt++) {
-    char* cur = smem + ((kt - kt0) & 1) * STAGE_BYTES;
-    char* nxt = smem + ((kt - kt0 + 1) & 1) * STAGE_BYTES;
-    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt is in LDS for every wave; every wave is done reading tile kt-1
-    if (kt + 1 < kt1) {
-      stage_issue<BK, GLDS, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)(kt + 1) * BK, nxt, tid, wave_u, ra);
-      stage_issue<BK, GLDS, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)(kt + 1) * BK, nxt + A_BYTES, tid, wave_u, rb);
+  for (int it = 0; it < nkt; it++) {
+    char* cur = smem + (it % NS) * STAGE_BYTES;
+    char* nxt = smem + ((it + NS - 1) % NS) * STAGE_BYTES;
+    if constexpr (GLDS) {
+      // stage `it` must have landed; in steady state NS-2 younger stages stay in flight
+      if (it + NS - 2 <= nkt - 1) wait_vmcnt<(NS - 2) * LOADS>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // every wave's DMA for stage `it` landed; every wave finished reading stage it-1
+    } else {
+      __syncthreads();
+    }
+    if (it + NS - 1 < nkt) {
+      stage_issue<BK, GLDS, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)(kt0 + it + NS - 1) * BK, nxt, tid, wave_u, ra);
+      stage_issue<BK, GLDS, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)(kt0 + it + NS - 1) * BK, nxt + A_BYTES, tid, wave_u, rb);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ks++) {
@@ -167,7 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if constexpr (!GLDS) {
-      if (kt + 1 < kt1) {  // other buffer: nobody reads it until the next barrier
+      if (it + 1 < nkt) {  // other buffer: nobody reads it until the next barrier
         stage_commit<BK, BM, NT>(nxt, tid, ra);
         stage_commit<BK, BN, NT>(nxt + A_BYTES, tid, rb);
       }
@@ -269,12 +299,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
   }
 }
 
-template <int BK, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
+template <int BK, int NS, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
-  constexpr int smem = 2 * (BM + BN) * BK * 2;
+  constexpr int smem = NS * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, EPI, GLDS, BM, BN, WM, WN>,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, NS, EPI, GLDS, BM, BN, WM, WN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
@@ -297,7 +327,8 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
   b.ktiles_per = (nk + b.splitk - 1) / b.splitk;
   b.splitk = (nk + b.ktiles_per - 1) / b.ktiles_per;  // no empty slices
   const int nblk = b.tiles_m * b.tiles_n * b.splitk;
-  hipLaunchKernelGGL((gemm_nt_kernel<BK, EPI, GLDS, BM, BN, WM, WN>), dim3(nblk), dim3(WM * WN * 64), smem, stream, b);
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, NS, EPI, GLDS, BM, BN, WM, WN>), dim3(nblk), dim3(WM * WN * 64), smem, stream,
+                     b);
   VJ_LAUNCH_CHECK("vj_gemm_bf16_nt");
   if (b.splitk > 1) {
     const int64_t n4 = a.M * a.N / 4;
@@ -310,26 +341,30 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
   return 0;
 }
 
-// flags: bit0 = register-staged operands (A/B testing); bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256)
+// flags: bit0 = register-staged operands (A/B testing); bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256);
+//        bits 6-7 = pipeline (0 auto, 1 = BK64 double buffer, 2 = BK32 4-stage ring with counted vmcnt)
 template <int EPI>
 static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   const bool reg_staged = (flags & 1) != 0;
   int cfg = (flags >> 4) & 3;
-  if (a.K % 64 != 0) cfg = 1;  // the K%32 fallback exists only for the small tile
+  int pipe = (flags >> 6) & 3;
   if (cfg == 0) {
     // 256x256 halves the L2->LDS traffic per flop but needs enough tiles to keep 256 CUs busy in whole waves
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
     cfg = (EPI != EPI_F32 && t256 >= 1024) ? 2 : 1;  // measured on the ViT-L step shapes (tools/gemm_bench.py)
   }
-  if (cfg == 2) {
-    return reg_staged ? launch_gemm<64, EPI, false, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
-                      : launch_gemm<64, EPI, true, 256, 256, 2, 4>(a, ws, ws_bytes, stream);
+  if (pipe == 0) pipe = 1;       // measured: the BK64 double buffer beats the BK32 ring on every step shape
+  if (a.K % 64 != 0) pipe = 2;   // K % 32 only fits the BK32 pipeline
+  if (reg_staged) {
+    if (a.K % 64 != 0) return launch_gemm<32, 2, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
+    return cfg == 2 ? launch_gemm<64, 2, EPI, false, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
+                    : launch_gemm<64, 2, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
   }
-  if (a.K % 64 == 0)
-    return reg_staged ? launch_gemm<64, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream)
-                      : launch_gemm<64, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
-  return reg_staged ? launch_gemm<32, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream)
-                    : launch_gemm<32, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
+  if (pipe == 1)
+    return cfg == 2 ? launch_gemm<64, 2, EPI, true, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
+                    : launch_gemm<64, 2, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
+  return cfg == 2 ? launch_gemm<32, 4, EPI, true, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
+                  : launch_gemm<32, 4, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
 }
 
 static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,

@@ -23,6 +23,36 @@ from .weights import BlockW, EncoderW, LinearW, PredictorW
 LN_EPS = 1e-6  # partial(nn.LayerNorm, eps=1e-6), vision_transformer.py:252-281 / predictor.py:242-246
 
 
+class SideStream:
+    """Second HIP stream for work that is off the critical path of the backward chain: the weight-gradient
+    GEMMs (and the transposes feeding them) only feed the optimizer, so they run concurrently with the dgrad
+    chain and fill the tail / launch bubbles of its ~100 us kernels.  `fork` makes the side stream wait for
+    everything enqueued so far on the main stream; `join` makes the main stream wait for the side stream."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.enabled = True
+
+    def fork(self, *tensors):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        for t in tensors:          # allocator plumbing: these buffers are read on the side stream
+            if t is not None:
+                t.record_stream(self.stream)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+_SIDE = {}
+
+
+def side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = SideStream(device)
+    return s
+
+
 @dataclass
 class Seg:
     """A group of B equal-length sequences occupying rows [row0, row0 + B*S) of the token matrix."""
@@ -61,11 +91,22 @@ def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
     return x2, saved
 
 
-def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None):
-    """dW (fp32, into lw.gw) = alpha * dy^T x_in ; db = alpha * colsum(dy) ; returns dx = dy W (bf16)."""
+def _wgrad(dy, x_in, lw: LinearW, alpha: float):
     dyT = ops.transpose_colsum(dy, lw.gb, alpha=alpha) if lw.gb is not None else ops.transpose(dy)
     xT = ops.transpose(x_in)
     ops.gemm_wgrad(dyT, xT, lw.gw, alpha=alpha)
+
+
+def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None):
+    """dW (fp32, into lw.gw) = alpha * dy^T x_in ; db = alpha * colsum(dy) ; returns dx = dy W (bf16).
+    The weight-gradient half goes to the side stream; the caller joins before the gradients are consumed."""
+    side = side_stream(dy.device)
+    if side.enabled:
+        side.fork(dy, x_in)
+        with torch.cuda.stream(side.stream):
+            _wgrad(dy, x_in, lw, alpha)
+    else:
+        _wgrad(dy, x_in, lw, alpha)
     if not need_dx:
         return None
     if dgelu_aux is not None:
@@ -132,8 +173,10 @@ def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_don
         dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha)
         saved_blocks[li] = None
         if on_layer_done is not None:
+            side_stream(dout.device).join()   # this layer's wgrads must be complete before its bucket goes out
             on_layer_done("enc", li)
     _linear_backward(dx, tok, ew.patch, alpha, need_dx=False)
+    side_stream(dout.device).join()
     if on_layer_done is not None:
         on_layer_done("enc", -1)
 
@@ -185,11 +228,13 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
     for sg, psg, tsg in zip(enc_segs, segs, tsegs):
         ops.copy_rows(_rows(dt, tsg), _rows(dx, psg), psg.B, tsg.S, 0, psg.S, sg.S, tsg.S, Dp)
     if on_layer_done is not None:
+        side_stream(dzhat.device).join()
         on_layer_done("pred", len(pw.blocks))
     for li in range(len(pw.blocks) - 1, -1, -1):
         dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha)
         saved_blocks[li] = None
         if on_layer_done is not None:
+            side_stream(dzhat.device).join()
             on_layer_done("pred", li)
     # token assembly backward: mask-token grads = sum of the target rows; context rows flow to predictor_embed
     de = torch.empty(e_shape, dtype=torch.bfloat16, device=dzhat.device)
@@ -204,6 +249,7 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
         if ti not in used:
             pw.g_mask_tokens[ti].zero_()
     dz = _linear_backward(de, z, pw.embed, alpha)
+    side_stream(dzhat.device).join()
     if on_layer_done is not None:
         on_layer_done("pred", -1)
     return dz

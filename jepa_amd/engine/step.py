@@ -18,7 +18,7 @@ import torch
 
 from ..hip import ops
 from . import dp
-from .layers import encoder_backward, encoder_forward, predictor_backward, predictor_forward
+from .layers import encoder_backward, encoder_forward, predictor_backward, predictor_forward, side_stream
 from .weights import ParamArena, encoder_views, is_no_decay, predictor_views
 
 
@@ -163,10 +163,21 @@ class Trainer:
         B = clips.shape[0]
         D = self.vit.embed_dim
         n_masks = len(masks_pred)
-        # ---- forward
-        h = self.forward_target(clips, masks_pred)
+        # ---- forward: the EMA target branch is independent of the context branch until the loss, so it runs on
+        #      the side stream concurrently (fills the tails of each other's kernels)
+        side = side_stream(self.device)
+        if side.enabled:
+            side.fork(clips, *masks_pred)
+            with torch.cuda.stream(side.stream):
+                h = self.forward_target(clips, masks_pred)
+        else:
+            h = self.forward_target(clips, masks_pred)
         z, segs, saved_e = encoder_forward(self.ew, clips, masks_enc, save=True)
         zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, masks_enc, masks_pred, save=True)
+        if side.enabled:
+            side.join()
+            for t in h:
+                t.record_stream(torch.cuda.current_stream())
         # ---- loss (train.py:440-459) and its gradient; |grad| carried as {+-s_i} in bf16, the common factor
         #      alpha = 1/(numel_min * n_masks) is applied in fp32 where parameter gradients are written
         numels = [t.rows * D for t in tsegs]
@@ -182,8 +193,9 @@ class Trainer:
         ops.reg_finish(pstd, n_masks, self._stat[1:2])
         # ---- backward (predictor first, then encoder layers 23..0); gradient buckets go out as layers finish
         self.reducer.begin()
-        dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=self.reducer.layer_done)
-        encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=self.reducer.layer_done)
+        hook = self.reducer.layer_done if self.reducer.enabled else None
+        dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=hook)
+        encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=hook)
         self.reducer.finish()
         # ---- clip / AdamW / EMA / bf16 re-cast (train.py:461-487)
         norms = self.optimizer_step(lr, wd, ema, clip_now)

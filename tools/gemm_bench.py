@@ -27,12 +27,12 @@ SHAPES = [  # (tag, M, N, K, epilogue)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--cfgs", default="1,2")
+    ap.add_argument("--cfgs", default="1.1,1.2,2.1,2.2", help="tile.pipeline pairs (see gemm.hip dispatch_gemm)")
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
-    cfgs = [int(c) for c in args.cfgs.split(",")]
-    print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " + " ".join(f"cfg{c:>2d}(TF/s)" for c in cfgs))
+    cfgs = [tuple(int(v) for v in c.split(".")) for c in args.cfgs.split(",")]
+    print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " + " ".join(f"t{c}p{q}(TF/s)" for c, q in cfgs))
     for tag, M, N, K, epi in SHAPES:
         A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
         B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
@@ -40,8 +40,8 @@ def main():
         aux = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16) if epi in (1, 2) else None
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
         res = []
-        for c in cfgs:
-            flags = c << 4
+        for c, q in cfgs:
+            flags = (c << 4) | (q << 6)
 
             def run():
                 if epi == 3:
