@@ -16,6 +16,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvjepa_hip.so")
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-ffp-contract=fast"]
+# per-file flags: the attention kernels do VALU math (softmax, dS) on MFMA results every tile, so their accumulators
+# must live in VGPRs (gfx950 has a unified VGPR/AGPR file): this removes ~1900 v_accvgpr_read/write moves.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():
@@ -33,9 +36,9 @@ def _newer(target, deps):
 
 
 def _compile(src, obj, headers):
-    if not _newer(obj, [src] + headers):
+    if not _newer(obj, [src, os.path.abspath(__file__)] + headers):
         return obj, False
-    cmd = [_hipcc()] + CXXFLAGS + ["-x", "hip", "-c", src, "-o", obj]
+    cmd = [_hipcc()] + CXXFLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

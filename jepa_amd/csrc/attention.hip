@@ -27,6 +27,8 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+#define DEFER_LOG2 5.0f  // forward softmax: rescale O only when a row max grows by more than 2^5
+
 template <int HDP>
 __device__ __forceinline__ int rm_swz(int row) {
   return HDP >= 64 ? (row & 7) : 0;
@@ -195,8 +197,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int r = 0; r < 4; r++) mx = fmaxf(mx, sacc[qt][kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrun[qt], mx * sc);   // sc > 0: max commutes with the scaling
-      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      // deferred rescale: keep the old running max unless some row of this wave grew by more than 2^DEFER_LOG2;
+      // P is then bounded by 2^DEFER_LOG2 instead of 1 (bf16 rounding is scale-free, fp32 accumulators have the
+      // headroom), and the O / l rescale -- a full pass over the accumulators -- is skipped on most tiles.
+      const float mcand = mx * sc;   // sc > 0: max commutes with the scaling
+      float mnew = mrun[qt];
+      if (__any(mcand > mrun[qt] + DEFER_LOG2)) {   // wave-uniform; first tile always (mrun = -inf)
+        mnew = fmaxf(mrun[qt], mcand);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+        lrun[qt] *= alpha;
+        mrun[qt] = mnew;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) oacc[qt][dt] *= alpha;
+      }
       float ls = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; kt++)
@@ -206,10 +219,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
           sacc[qt][kt][r] = p;
           ls += p;
         }
-      lrun[qt] = lrun[qt] * alpha + ls;
-      mrun[qt] = mnew;
-#pragma unroll
-      for (int dt = 0; dt < DT; dt++) oacc[qt][dt] *= alpha;
+      lrun[qt] += ls;
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         u32x4_t pw;
