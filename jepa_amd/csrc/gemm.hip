@@ -13,25 +13,7 @@
 // caller asks for it.  The MFMA is issued with swapped operands (D = Bfrag x Afrag) so each lane owns four
 // CONSECUTIVE output columns: 8-byte bf16 / 16-byte fp32 epilogue accesses for C, bias, residual and aux.
 // Workgroup ids are remapped so every XCD (private L2) works on a contiguous band of tiles.
-#include "common.hpp"
-
-enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_F32 = 3 };
-
-struct GemmArgs {
-  const bf16_t* A;
-  const bf16_t* B;
-  void* C;
-  const float* bias;      // [N] fp32, nullable
-  const bf16_t* res;      // [M,N] bf16 residual, nullable (EPI_BF16)
-  const bf16_t* aux_in;   // [M,N] bf16 pre-activation u (EPI_DGELU)
-  bf16_t* aux_out;        // [M,N] bf16 pre-activation u out, nullable (EPI_GELU)
-  int64_t M, N, K, lda, ldb, ldc, ldr, ldaux;
-  float alpha, beta;
-  int tiles_m, tiles_n;
-  int splitk;          // > 1: K is cut into `splitk` slices, raw fp32 partials go to ws[slice][M][N] (EPI_F32 only)
-  int ktiles_per;      // K-tiles per slice
-  float* ws;
-};
+#include "gemm_common.hpp"
 
 // tile configurations: <BM, BN, WM, WN> = block tile and wave grid; each wave owns (BM/WM) x (BN/WN)
 //   128x128, 2x2 waves (64x64 per wave)  : 64 KB LDS, 2 workgroups / CU -- small / skinny problems
@@ -204,71 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     }
   }
 
-  // ---- epilogue: lane owns rows m = .. + (lane&15), columns n = .. + 4*(lane>>4) + {0,1,2,3} ----
-#pragma unroll
-  for (int i = 0; i < FM; i++) {
-    const int64_t m = m0 + wm * (FM * 16) + i * 16 + frow;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < FN; j++) {
-      const int64_t n = n0 + wn * (FN * 16) + j * 16 + fg * 4;
-      if (n >= p.N) continue;  // N % 4 == 0 is enforced by the host wrapper
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if constexpr (EPI == EPI_F32) {
-        if (p.splitk > 1) {  // raw partial; alpha/beta are applied by the slice reduction
-          *(float4*)(p.ws + ((int64_t)slice * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-          continue;
-        }
-        float* cp = (float*)p.C + m * p.ldc + n;
-        float4 o = make_float4(v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha);
-        if (p.beta != 0.f) {
-          const float4 c0 = *(const float4*)cp;
-          o.x += p.beta * c0.x;
-          o.y += p.beta * c0.y;
-          o.z += p.beta * c0.z;
-          o.w += p.beta * c0.w;
-        }
-        *(float4*)cp = o;
-      } else {
-        if (p.bias) {
-          const float4 b4 = *(const float4*)(p.bias + n);
-          v[0] += b4.x;
-          v[1] += b4.y;
-          v[2] += b4.z;
-          v[3] += b4.w;
-        }
-        if constexpr (EPI == EPI_GELU) {
-          u32x2_t u;
-          u[0] = pack_bf2(v[0], v[1]);
-          u[1] = pack_bf2(v[2], v[3]);
-          if (p.aux_out) *(u32x2_t*)(p.aux_out + m * p.ldaux + n) = u;
-          // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
-          v[0] = gelu_f(bf_lo(u[0]));
-          v[1] = gelu_f(bf_hi(u[0]));
-          v[2] = gelu_f(bf_lo(u[1]));
-          v[3] = gelu_f(bf_hi(u[1]));
-        } else if constexpr (EPI == EPI_DGELU) {
-          const u32x2_t u = *(const u32x2_t*)(p.aux_in + m * p.ldaux + n);
-          v[0] *= dgelu_f(bf_lo(u[0]));
-          v[1] *= dgelu_f(bf_hi(u[0]));
-          v[2] *= dgelu_f(bf_lo(u[1]));
-          v[3] *= dgelu_f(bf_hi(u[1]));
-        } else {
-          if (p.res) {
-            const u32x2_t r2 = *(const u32x2_t*)(p.res + m * p.ldr + n);
-            v[0] += bf_lo(r2[0]);
-            v[1] += bf_hi(r2[0]);
-            v[2] += bf_lo(r2[1]);
-            v[3] += bf_hi(r2[1]);
-          }
-        }
-        u32x2_t o;
-        o[0] = pack_bf2(v[0], v[1]);
-        o[1] = pack_bf2(v[2], v[3]);
-        *(u32x2_t*)((bf16_t*)p.C + m * p.ldc + n) = o;
-      }
-    }
-  }
+  gemm_epilogue<EPI, FM, FN>(p, acc, m0 + wm * (FM * 16), n0 + wn * (FN * 16), frow, fg, slice);
 }
 
 // out[m][n] = alpha * sum_s ws[s][m][n] + beta * out[m][n]   (deterministic split-K combine)
@@ -342,19 +260,29 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
 }
 
 // flags: bit0 = register-staged operands (A/B testing); bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256);
-//        bits 6-7 = pipeline (0 auto, 1 = BK64 double buffer, 2 = BK32 4-stage ring with counted vmcnt)
+//        bits 6-7 = pipeline (0 auto, 1 = BK64 double buffer, 2 = BK32 4-stage ring with counted vmcnt,
+//                   3 = 256x256 staggered 8-phase schedule, gemm8.hip)
+int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, hipStream_t stream);  // gemm8.hip
+
 template <int EPI>
 static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   const bool reg_staged = (flags & 1) != 0;
   int cfg = (flags >> 4) & 3;
   int pipe = (flags >> 6) & 3;
-  if (cfg == 0) {
-    // 256x256 halves the L2->LDS traffic per flop but needs enough tiles to keep 256 CUs busy in whole waves
+  const bool is_wgrad = (EPI == EPI_F32 && ws != nullptr);
+  if (pipe == 0 && cfg == 0) {
+    // measured on the ViT-L step shapes (tools/gemm_bench.py): the staggered 8-phase 256x256 kernel wins on every
+    // forward / dgrad shape with >= ~90 tiles except the N=1152, K=384 predictor qkv; split-K wgrads (few tiles,
+    // long K) stay on 128x128 with 2 workgroups per CU.
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
-    cfg = (EPI != EPI_F32 && t256 >= 1024) ? 2 : 1;  // measured on the ViT-L step shapes (tools/gemm_bench.py)
+    const bool narrow = (a.K < 512 && a.N > 1024 && a.N < 1536);
+    if (!is_wgrad && a.K % 64 == 0 && t256 >= 90 && !narrow) pipe = 3;
   }
-  if (pipe == 0) pipe = 1;       // measured: the BK64 double buffer beats the BK32 ring on every step shape
+  if (cfg == 0) cfg = 1;
+  if (pipe == 0) pipe = 1;       // BK64 double buffer (beats the BK32 ring on every step shape)
   if (a.K % 64 != 0) pipe = 2;   // K % 32 only fits the BK32 pipeline
+  if (pipe == 3 && a.K % 64 == 0 && !reg_staged && !is_wgrad) return vj_gemm_launch_8phase(a, EPI, stream);
+  if (pipe == 3) pipe = 1;
   if (reg_staged) {
     if (a.K % 64 != 0) return launch_gemm<32, 2, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
     return cfg == 2 ? launch_gemm<64, 2, EPI, false, 256, 256, 2, 4>(a, ws, ws_bytes, stream)

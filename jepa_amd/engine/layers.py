@@ -30,8 +30,9 @@ class SideStream:
     everything enqueued so far on the main stream; `join` makes the main stream wait for the side stream."""
 
     def __init__(self, device):
+        import os
         self.stream = torch.cuda.Stream(device=device)
-        self.enabled = True
+        self.enabled = os.environ.get("VJ_NO_OVERLAP", "0") != "1"   # serial mode for per-kernel profiling
 
     def fork(self, *tensors):
         self.stream.wait_stream(torch.cuda.current_stream())

@@ -27,7 +27,7 @@ SHAPES = [  # (tag, M, N, K, epilogue)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--cfgs", default="1.1,1.2,2.1,2.2", help="tile.pipeline pairs (see gemm.hip dispatch_gemm)")
+    ap.add_argument("--cfgs", default="1.1,2.1,2.3", help="tile.pipeline pairs (see gemm.hip dispatch_gemm)")
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
