@@ -85,6 +85,9 @@ int vj_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ld
 /* out[N, Mpad] = in[M,N]^T (zero padded): the wgrad operands dY^T, X^T; weight shadows W^T for dgrad. */
 int vj_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,
                       vj_stream_t stream);
+/* one launch for many transposes (all W^T dgrad shadows after an optimizer step): desc = device array of
+ * {src, dst, M, N, ld_in, Mpad} (6 x int64 per tensor), blocks = device int32[4*n_blocks] {tensor, tile_m, tile_n, 0} */
+int vj_transpose_multi(const void* desc, const void* blocks, int64_t n_blocks, vj_stream_t stream);
 /* transpose + bias gradient in ONE pass over dY: colsum[n] = alpha*sum_m in[m][n] + beta*colsum[n] */
 int64_t vj_transpose_colsum_ws_bytes(int64_t M, int64_t N);
 int vj_transpose_colsum_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,

@@ -398,23 +398,51 @@ extern "C" int vj_latent_loss(const void* z_bf16, const float* h, void* dz_bf16,
 // token_pstd: pstd[b,d] (+)= sqrt(unbiased_var_k z[b,k,d] + 1e-4)   (reg_fn, train.py:448-449)
 // one block per (b, 256-column slab); two-pass over the K rows for accuracy.
 // ---------------------------------------------------------------------------------------------
+// one workgroup per (b, 64-column slab): 4 waves split the K rows, each lane owns one column pair... 8 columns per
+// thread (16-byte loads), shifted single-pass sums (shift = first row) combined across the 8 row-lanes in LDS.
 __global__ __launch_bounds__(256) void token_pstd_kernel(const bf16_t* __restrict__ z, float* __restrict__ pstd,
                                                          int64_t K, int D, int accumulate) {
+  __shared__ float red[2][32][65];
   const int64_t b = blockIdx.y;
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  const bf16_t* zp = z + b * K * D + d;
-  float s = 0.f;
-  for (int64_t k = 0; k < K; k++) s += bf2f(zp[k * D]);
-  const float mean = s / (float)K;
-  float q = 0.f;
-  for (int64_t k = 0; k < K; k++) {
-    const float t = bf2f(zp[k * D]) - mean;
-    q += t * t;
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;       // 8 column groups of 8, 32 row lanes
+  const int d0 = blockIdx.x * 64 + cg * 8;
+  const bf16_t* zp = z + b * K * D;
+  float s[8], q[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) s[j] = q[j] = sh[j] = 0.f;
+  if (d0 < D) {
+    load8(zp + d0, sh);                                         // shift by row 0: well-conditioned single pass
+    for (int64_t k = rl; k < K; k += 32) {
+      float v[8];
+      load8(zp + k * D + d0, v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const float t = v[j] - sh[j];
+        s[j] += t;
+        q[j] += t * t;
+      }
+    }
   }
-  const float v = sqrtf(q / (float)(K - 1) + 1e-4f);
-  float* o = pstd + b * D + d;
-  *o = accumulate ? (*o + v) : v;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    red[0][rl][cg * 8 + j] = s[j];
+    red[1][rl][cg * 8 + j] = q[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x, d = blockIdx.x * 64 + c;
+    if (d < D) {
+      float ss = 0.f, qq = 0.f;
+      for (int r = 0; r < 32; r++) {
+        ss += red[0][r][c];
+        qq += red[1][r][c];
+      }
+      const float var = (qq - ss * ss / (float)K) / (float)(K - 1);   // unbiased, shift-invariant
+      const float v = sqrtf(fmaxf(var, 0.f) + 1e-4f);
+      float* o = pstd + b * D + d;
+      *o = accumulate ? (*o + v) : v;
+    }
+  }
 }
 
 // reg = mean(relu(1 - pstd_sum / n_masks))
@@ -433,7 +461,8 @@ extern "C" int vj_token_pstd(const void* z_bf16, float* pstd, int64_t B, int64_t
                              hipStream_t stream) {
   VJ_CHECK_ARG(K >= 2, "vj_token_pstd: need at least 2 tokens for an unbiased variance (K=%ld)", (long)K);
   if (B * D == 0) return 0;
-  hipLaunchKernelGGL(token_pstd_kernel, dim3((unsigned)cdiv64(D, 256), (unsigned)B), dim3(256), 0, stream,
+  VJ_CHECK_ARG(D % 8 == 0, "vj_token_pstd: D must be a multiple of 8");
+  hipLaunchKernelGGL(token_pstd_kernel, dim3((unsigned)cdiv64(D, 64), (unsigned)B), dim3(256), 0, stream,
                      (const bf16_t*)z_bf16, pstd, K, (int)D, accumulate);
   VJ_LAUNCH_CHECK("vj_token_pstd");
   return 0;

@@ -438,3 +438,54 @@ extern "C" int vj_copy_rows(const void* src, void* dst, int64_t B, int64_t src_r
   VJ_LAUNCH_CHECK("vj_copy_rows");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// transpose_multi: ONE launch that transposes many bf16 matrices (the W^T dgrad shadows of every Linear, refreshed
+// once per optimizer step).  desc[t] = {src, dst, M, N, ld_in, Mpad}; blocks[b] = {tensor, tile_m, tile_n, 0}.
+// ---------------------------------------------------------------------------------------------
+struct TransposeDesc {
+  const bf16_t* src;
+  bf16_t* dst;
+  int64_t M, N, ld_in, Mpad;
+};
+
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const TransposeDesc* __restrict__ desc,
+                                                              const int4* __restrict__ blocks) {
+  __shared__ bf16_t tile[64][66];
+  const int4 bi = blocks[blockIdx.x];
+  const TransposeDesc d = desc[bi.x];
+  const int64_t m0 = (int64_t)bi.y * 64, n0 = (int64_t)bi.z * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int q = t + it * 256;
+    const int r = q >> 3, c = (q & 7) * 8;
+    u32x4_t v = {0, 0, 0, 0};
+    if (m0 + r < d.M && n0 + c < d.N) v = *(const u32x4_t*)(d.src + (m0 + r) * d.ld_in + n0 + c);
+#pragma unroll
+    for (int i = 0; i < 4; i++) *(uint32_t*)&tile[r][c + 2 * i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int q = t + it * 256;
+    const int n = q >> 3, mc = (q & 7) * 8;
+    if (n0 + n < d.N && m0 + mc < d.Mpad) {
+      u32x4_t o;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        o[i] = (uint32_t)tile[mc + 2 * i][n] | ((uint32_t)tile[mc + 2 * i + 1][n] << 16);
+      *(u32x4_t*)(d.dst + (n0 + n) * d.Mpad + m0 + mc) = o;
+    }
+  }
+}
+
+// desc: device array of 6 x int64 per tensor {src, dst, M, N, ld_in, Mpad}; blocks: device int32[4*n_blocks]
+extern "C" int vj_transpose_multi(const void* desc, const void* blocks, int64_t n_blocks, hipStream_t stream) {
+  if (n_blocks == 0) return 0;
+  VJ_CHECK_ARG(n_blocks < (1ll << 31), "vj_transpose_multi: too many blocks");
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream,
+                     (const TransposeDesc*)desc, (const int4*)blocks);
+  VJ_LAUNCH_CHECK("vj_transpose_multi");
+  return 0;
+}

@@ -146,10 +146,29 @@ class ParamArena:
             self.wT[n] = torch.empty((w2.shape[1], ops.pad64(w2.shape[0])), dtype=torch.bfloat16, device=self.device)
         self.refresh_transposed()
 
-    def refresh_transposed(self):
-        for n, t in self.wT.items():
+    def _build_transpose_plan(self):
+        """Device-side descriptor / block tables for the single-launch refresh of every W^T shadow."""
+        desc, blocks = [], []
+        for ti, (n, t) in enumerate(self.wT.items()):
             w = self.bf16(n)
-            ops.transpose(w.reshape(w.shape[0], -1), out=t)
+            w2 = w.reshape(w.shape[0], -1)
+            M, N = w2.shape                      # W [N_out, K_in] -> W^T [K_in, pad64(N_out)]
+            Mp = t.shape[1]
+            desc += [w2.data_ptr(), t.data_ptr(), M, N, w2.stride(0), Mp]
+            for tm in range((Mp + 63) // 64):
+                for tn in range((N + 63) // 64):
+                    blocks += [ti, tm, tn, 0]
+        self._tp_desc = torch.tensor(desc, dtype=torch.int64, device=self.device)
+        self._tp_blocks = torch.tensor(blocks, dtype=torch.int32, device=self.device)
+        self._tp_n = len(blocks) // 4
+        self._tp_key = tuple(self.wT.keys())
+
+    def refresh_transposed(self):
+        if not self.wT:
+            return
+        if getattr(self, "_tp_key", None) != tuple(self.wT.keys()):
+            self._build_transpose_plan()
+        ops.transpose_multi(self._tp_desc, self._tp_blocks, self._tp_n)
 
 
 def _lin(arena, prefix, train, w_shape2d=None):

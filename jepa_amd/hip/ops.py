@@ -230,6 +230,11 @@ def transpose(x, M=None, out=None, stream=None):
     return out
 
 
+def transpose_multi(desc, blocks, n_blocks, stream=None):
+    lib = load_library()
+    check(lib.vj_transpose_multi(_ptr(desc), _ptr(blocks), n_blocks, _stream(stream)), "vj_transpose_multi")
+
+
 def colsum(x, out, M=None, alpha=1.0, accumulate=False, group=0, row_lo=0, row_hi=None, stream=None):
     """out[n] (fp32) = alpha * sum_m x[m,n] (+ out); optional per-sample row window for the mask-token grad."""
     lib = load_library()
