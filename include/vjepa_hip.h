@@ -105,6 +105,8 @@ int vj_reduce_partials(const float* part, float* out, int64_t P, int64_t N, floa
  * lse2: [B,H,S] fp32 log2-sum-exp saved for the backward (nullable in inference).  hd % 8 == 0, hd <= 128. */
 int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd, float scale,
                 vj_stream_t stream);
+/* tuning switch (benchmarks only): 16-row query tiles per wave in the forward kernel, 2 (default) or 1 */
+int vj_attn_set_variant(int fwd_qt);
 int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H);
 /* dqkv [B,S,3,H,hd] <- (dout [B,S,H*hd], saved qkv, o, lse2) */
 int vj_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B,

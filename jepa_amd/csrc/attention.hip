@@ -35,17 +35,17 @@ __device__ __forceinline__ int rm_swz(int row) {
 }
 
 // ---- row-major image: 64 rows x HDP, 16-byte chunks XOR-swizzled --------------------------------------------
-template <int HDP>
+template <int HDP, int NT = 256>
 struct RowTile {
   static constexpr int CHP = HDP / 8;
-  static constexpr int NIT = (64 * CHP + 255) / 256;
+  static constexpr int NIT = (64 * CHP + NT - 1) / NT;
   static constexpr int BYTES = 64 * HDP * 2;
   // base: pointer to element [row 0][col 0] of this (b,h) slice; rs: row stride in elements
   static __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int64_t rs, int r0, int nrows, int hd,
                                               int tid, u32x4_t* regs) {
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
-      const int item = tid + it * 256;
+      const int item = tid + it * NT;
       const int row = item / CHP, ch = item % CHP;
       u32x4_t v = {0, 0, 0, 0};
       if (item < 64 * CHP && r0 + row < nrows && ch * 8 < hd) v = *(const u32x4_t*)(base + (int64_t)(r0 + row) * rs + ch * 8);
@@ -55,7 +55,7 @@ struct RowTile {
   static __device__ __forceinline__ void store(char* lds, int tid, const u32x4_t* regs) {
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
-      const int item = tid + it * 256;
+      const int item = tid + it * NT;
       const int row = item / CHP, ch = item % CHP;
       if (item < 64 * CHP) *(u32x4_t*)(lds + row * (HDP * 2) + ((ch ^ rm_swz<HDP>(row)) * 16)) = regs[it];
     }
@@ -112,13 +112,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // =============================================================================================================
 // forward:  O = softmax(Q K^T * scale) V,  128 queries per workgroup (32 per wave), 64-key tiles
 // =============================================================================================================
-template <int HDP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+template <int HDP, int QT>
+__global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                        float* __restrict__ lse2, int B, int S, int H, int hd,
                                                        float sc, int nqb) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES];
-  char* k_lds = smem;
-  char* v_lds = smem + RowTile<HDP>::BYTES;
+  constexpr int NT = 8 * 64 / QT;   // 128 queries per workgroup, 16*QT per wave
+  using RT = RowTile<HDP, NT>;
+  __shared__ __attribute__((aligned(16))) char smem[4 * RT::BYTES];   // {K,V} x 2 buffers
   const TrFrag<HDP> trf(threadIdx.x & 63);
   constexpr int KS = HDP / 32, DT = HDP / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -130,59 +130,76 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
   const bf16_t* kbase = qbase + (int64_t)H * hd;
   const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
-  const int q0 = qb * 128 + w * 32;
+  const int q0 = qb * 128 + w * (16 * QT);
 
-  bf16x8_t qf[2][KS];
+  bf16x8_t qf[QT][KS];
 #pragma unroll
-  for (int qt = 0; qt < 2; qt++)
+  for (int qt = 0; qt < QT; qt++)
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
       const int q = q0 + qt * 16 + li, d0 = ks * 32 + 8 * g;
       qf[qt][ks] = load_frag_global(qbase + (int64_t)q * rs + d0, q < S && d0 < hd);
     }
 
-  f32x4_t oacc[2][DT];
+  f32x4_t oacc[QT][DT];
 #pragma unroll
-  for (int qt = 0; qt < 2; qt++)
+  for (int qt = 0; qt < QT; qt++)
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) oacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; qt++) {
+    mrun[qt] = -INFINITY;
+    lrun[qt] = 0.f;
+  }
 
-  u32x4_t kreg[RowTile<HDP>::NIT], vreg[RowTile<HDP>::NIT];
+  u32x4_t kreg[RT::NIT], vreg[RT::NIT];
   const int nt = (S + 63) / 64;
-  RowTile<HDP>::load(kbase, rs, 0, S, hd, tid, kreg);
-  RowTile<HDP>::load(vbase, rs, 0, S, hd, tid, vreg);
+  // double-buffered LDS image, ONE barrier per tile: tile t+1 is written into the other buffer right after the
+  // barrier of tile t (its global loads were issued a whole tile earlier), tile t+2's loads are issued next.
+  RT::load(kbase, rs, 0, S, hd, tid, kreg);
+  RT::load(vbase, rs, 0, S, hd, tid, vreg);
+  RT::store(smem, tid, kreg);
+  RT::store(smem + RT::BYTES, tid, vreg);
+  if (nt > 1) {
+    RT::load(kbase, rs, 64, S, hd, tid, kreg);
+    RT::load(vbase, rs, 64, S, hd, tid, vreg);
+  }
 
   for (int t = 0; t < nt; t++) {
     const int k0 = t * 64;
-    __syncthreads();  // every wave is done with the previous tile's LDS image
-    RowTile<HDP>::store(k_lds, tid, kreg);
-    RowTile<HDP>::store(v_lds, tid, vreg);
-    __syncthreads();
-    if (t + 1 < nt) {  // next tile's loads fly under this tile's MFMAs
-      RowTile<HDP>::load(kbase, rs, k0 + 64, S, hd, tid, kreg);
-      RowTile<HDP>::load(vbase, rs, k0 + 64, S, hd, tid, vreg);
+    char* k_lds = smem + (t & 1) * (2 * RT::BYTES);
+    char* v_lds = k_lds + RT::BYTES;
+    __syncthreads();  // tile t is in LDS for every wave; every wave is done reading tile t-1 (the other buffer)
+    if (t + 1 < nt) {
+      char* kn = smem + ((t + 1) & 1) * (2 * RT::BYTES);
+      RT::store(kn, tid, kreg);
+      RT::store(kn + RT::BYTES, tid, vreg);
+      if (t + 2 < nt) {
+        RT::load(kbase, rs, k0 + 128, S, hd, tid, kreg);
+        RT::load(vbase, rs, k0 + 128, S, hd, tid, vreg);
+      }
     }
     // ---- S^T = K Q^T : sacc[qt][kt] holds S^T[key = kt*16 + 4g + r][q = li] ----
-    f32x4_t sacc[2][4];
+    f32x4_t sacc[QT][4];
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++)
+    for (int qt = 0; qt < QT; qt++)
 #pragma unroll
       for (int kt = 0; kt < 4; kt++) sacc[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 4; kt++)
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) {
-        const bf16x8_t kf = RowTile<HDP>::frag(k_lds, kt * 16 + li, ks * 4 + g);
+        const bf16x8_t kf = RT::frag(k_lds, kt * 16 + li, ks * 4 + g);
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++)
+        for (int qt = 0; qt < QT; qt++)
           sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], sacc[qt][kt], 0, 0, 0);
       }
     // ---- online softmax (query = li, reduced over r, kt in-lane and over g across lanes 16/32 apart) ----
-    bf16x8_t pf[2][2];
+    bf16x8_t pf[QT][2];
     const bool tail = (k0 + 64 > S);  // wave-uniform: only the last tile can hold padded keys
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
       if (tail) {
 #pragma unroll
         for (int kt = 0; kt < 4; kt++)
@@ -237,13 +254,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       for (int dt = 0; dt < DT; dt++) {
         const bf16x8_t vf = trf.load(v_lds, c * 32, dt * 16);
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++)
+        for (int qt = 0; qt < QT; qt++)
           oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
       }
   }
 
 #pragma unroll
-  for (int qt = 0; qt < 2; qt++) {
+  for (int qt = 0; qt < QT; qt++) {
     float l = lrun[qt];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -563,6 +580,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // =============================================================================================================
 // host entry points
 // =============================================================================================================
+static int g_attn_fwd_qt = 2;   // A/B switch for tools/attn_bench.py (vj_attn_set_variant)
+extern "C" int vj_attn_set_variant(int fwd_qt) {
+  g_attn_fwd_qt = (fwd_qt == 1) ? 1 : 2;
+  return 0;
+}
+
 static int pick_hdp(int64_t hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : (hd <= 128 ? 128 : 0)); }
 #define LOG2E 1.4426950408889634f
 
@@ -575,19 +598,23 @@ extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int
   const int64_t nblk = B * H * nqb;
   VJ_CHECK_ARG(nblk < (1ll << 31), "vj_attn_fwd: grid too large");
   const float sc = scale * LOG2E;
+  // QT = 16-row query tiles per wave (QT = 1: 8 waves / workgroup, half the registers per wave).  Measured on
+  // MI355X: QT = 2 is faster or equal for every head size (the kernel is bound by VALU issue, not by occupancy).
+#define VJ_FWD(HDPV, QTV)                                                                                            \
+  hipLaunchKernelGGL((attn_fwd_kernel<HDPV, QTV>), dim3((unsigned)nblk), dim3(8 * 64 / QTV), 0, stream,                \
+                     (const bf16_t*)qkv, (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb)
+  const int qt_sel = g_attn_fwd_qt;
   switch (pick_hdp(hd)) {
     case 32:
-      hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)qkv,
-                         (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb);
+      if (qt_sel == 2) VJ_FWD(32, 2); else VJ_FWD(32, 1);
       break;
     case 64:
-      hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)qkv,
-                         (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb);
+      if (qt_sel == 2) VJ_FWD(64, 2); else VJ_FWD(64, 1);
       break;
     default:
-      hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((unsigned)nblk), dim3(256), 0, stream, (const bf16_t*)qkv,
-                         (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb);
+      if (qt_sel == 2) VJ_FWD(128, 2); else VJ_FWD(128, 1);
   }
+#undef VJ_FWD
   VJ_LAUNCH_CHECK("vj_attn_fwd");
   return 0;
 }

@@ -262,7 +262,7 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
 // flags: bit0 = register-staged operands (A/B testing); bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256);
 //        bits 6-7 = pipeline (0 auto, 1 = BK64 double buffer, 2 = BK32 4-stage ring with counted vmcnt,
 //                   3 = 256x256 staggered 8-phase schedule, gemm8.hip)
-int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, hipStream_t stream);  // gemm8.hip
+int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);  // gemm8.hip
 
 template <int EPI>
 static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
@@ -277,11 +277,12 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
     const bool narrow = (a.K < 512 && a.N > 1024 && a.N < 1536);
     if (!is_wgrad && a.K % 64 == 0 && t256 >= 90 && !narrow) pipe = 3;
+    if (is_wgrad && a.K % 64 == 0 && t256 >= 64) pipe = 3;   // fc1/fc2 wgrads: 8-phase + split-K (1.05 vs 0.95 PF)
   }
   if (cfg == 0) cfg = 1;
   if (pipe == 0) pipe = 1;       // BK64 double buffer (beats the BK32 ring on every step shape)
   if (a.K % 64 != 0) pipe = 2;   // K % 32 only fits the BK32 pipeline
-  if (pipe == 3 && a.K % 64 == 0 && !reg_staged && !is_wgrad) return vj_gemm_launch_8phase(a, EPI, stream);
+  if (pipe == 3 && a.K % 64 == 0 && !reg_staged) return vj_gemm_launch_8phase(a, EPI, ws, ws_bytes, stream);
   if (pipe == 3) pipe = 1;
   if (reg_staged) {
     if (a.K % 64 != 0) return launch_gemm<32, 2, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream);

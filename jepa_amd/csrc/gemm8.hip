@@ -80,12 +80,15 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
   const bool late_group = wave_u >= 4;        // waves 4-7 run one barrier interval behind waves 0-3
   const int frow = lane & 15, fg = lane >> 4;
 
-  const int nblk = p.tiles_m * p.tiles_n;
-  const int logical = xcd_logical(blockIdx.x, nblk);
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int logical_all = xcd_logical(blockIdx.x, ntile * p.splitk);
+  const int slice = logical_all / ntile;
   int tm, tn;
-  tile_of(logical, p.tiles_m, p.tiles_n, tm, tn);
+  tile_of(logical_all - slice * ntile, p.tiles_m, p.tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * P8_BM, n0 = (int64_t)tn * P8_BN;
-  const int nk = (int)(p.K / P8_BK);
+  const int nk_all = (int)(p.K / P8_BK);
+  const int kt0 = slice * p.ktiles_per;                   // this workgroup's K-tile range (split-K for wgrads)
+  const int nk = (kt0 + p.ktiles_per < nk_all ? kt0 + p.ktiles_per : nk_all) - kt0;
   const int last_part = 4 * nk - 2;   // parts: -1 (A0 of tile 0), then per tile B0, B1, A1 and A0 of the next tile
 
   f32x4_t acc[8][4];
@@ -113,10 +116,10 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
   }
 
   // ---- prologue: parts -1 (A0 of tile 0), 0, 1, 2 in flight; part -1 landed for everyone
-  issue_part(p, -1, m0, n0, 0, smem, tid, wave_u);
+  issue_part(p, -1, m0, n0, kt0, smem, tid, wave_u);
 #pragma unroll
   for (int q = 0; q < 3; q++)
-    if (q <= last_part) issue_part(p, q, m0, n0, 0, smem, tid, wave_u);
+    if (q <= last_part) issue_part(p, q, m0, n0, kt0, smem, tid, wave_u);
   if (last_part >= 2) wait_vm<6>();
   else wait_vm<0>();
   bar();
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) ra0[i][ks] = *(const bf16x8_t*)(slot + a_off[i][ks]);
-    if (3 <= last_part) issue_part(p, 3, m0, n0, 0, smem, tid, wave_u);
+    if (3 <= last_part) issue_part(p, 3, m0, n0, kt0, smem, tid, wave_u);
     if (3 <= last_part) wait_vm<6>();
     else wait_vm<0>();
   }
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
           for (int ks = 0; ks < 2; ks++) ra0[i][ks] = *(const bf16x8_t*)(slot + a_off[i][ks]);
       }
       if (q + 4 <= last_part) {
-        issue_part(p, q + 4, m0, n0, 0, smem, tid, wave_u);
+        issue_part(p, q + 4, m0, n0, kt0, smem, tid, wave_u);
         wait_vm<6>();                              // part q+1 landed; q+2..q+4 in flight
       } else {                                     // tail: fewer younger parts behind part q+1
         const int younger = last_part - (q + 1);
@@ -213,11 +216,14 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
     }
   }
   if (!late_group) bar();   // the early group matches the late group's extra barrier
-  gemm_epilogue<EPI, 8, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, frow, fg, 0);
+  gemm_epilogue<EPI, 8, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, frow, fg, slice);
 }
 
+__global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, int64_t N, int64_t ldc, int S,
+                                     float alpha, float beta);   // gemm.hip
+
 template <int EPI>
-static int launch8(const GemmArgs& a, hipStream_t stream) {
+static int launch8(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
   constexpr int smem = 8 * PART_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
@@ -229,17 +235,37 @@ static int launch8(const GemmArgs& a, hipStream_t stream) {
   b.tiles_n = (int)cdiv64(a.N, P8_BN);
   b.splitk = 1;
   b.ws = nullptr;
-  hipLaunchKernelGGL(gemm_nt_8phase_kernel<EPI>, dim3(b.tiles_m * b.tiles_n), dim3(512), smem, stream, b);
+  const int nk = (int)(a.K / P8_BK);
+  if (EPI == EPI_F32 && ws != nullptr) {   // wgrad: one workgroup per CU needs >= ~256 of them; >= 8 K-tiles per slice
+    const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
+    int64_t s = cdiv64(256, tiles);
+    const int64_t max_by_k = nk / 8 > 0 ? nk / 8 : 1;
+    if (s > max_by_k) s = max_by_k;
+    while (s > 1 && s * a.M * a.N * 4 > ws_bytes) s--;
+    b.splitk = (int)s;
+    b.ws = (float*)ws;
+  }
+  b.ktiles_per = (nk + b.splitk - 1) / b.splitk;
+  b.splitk = (nk + b.ktiles_per - 1) / b.ktiles_per;
+  hipLaunchKernelGGL(gemm_nt_8phase_kernel<EPI>, dim3(b.tiles_m * b.tiles_n * b.splitk), dim3(512), smem, stream, b);
   VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(8-phase)");
+  if (b.splitk > 1) {
+    const int64_t n4 = a.M * a.N / 4;
+    int64_t g = cdiv64(n4, 256);
+    if (g > 256 * 8) g = 256 * 8;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float4*)b.ws,
+                       (float*)a.C, a.M, a.N, a.ldc, b.splitk, a.alpha, a.beta);
+    VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(8-phase splitk reduce)");
+  }
   return 0;
 }
 
 // entry used by gemm.hip's dispatcher (pipeline 3); requires K % 64 == 0
-int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, hipStream_t stream) {
+int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream) {
   switch (epilogue) {
-    case EPI_BF16: return launch8<EPI_BF16>(a, stream);
-    case EPI_GELU: return launch8<EPI_GELU>(a, stream);
-    case EPI_DGELU: return launch8<EPI_DGELU>(a, stream);
-    default: return launch8<EPI_F32>(a, stream);
+    case EPI_BF16: return launch8<EPI_BF16>(a, nullptr, 0, stream);
+    case EPI_GELU: return launch8<EPI_GELU>(a, nullptr, 0, stream);
+    case EPI_DGELU: return launch8<EPI_DGELU>(a, nullptr, 0, stream);
+    default: return launch8<EPI_F32>(a, ws, ws_bytes, stream);
   }
 }

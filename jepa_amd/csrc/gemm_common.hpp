@@ -26,57 +26,68 @@ struct GemmArgs {
 template <int EPI, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int64_t m_base,
                                               int64_t n_base, int frow, int fg, int slice) {
+  const int64_t ncol0 = n_base + fg * 4;   // this lane's first column; tile j adds j*16
+  float4 bias4[FN];
+  if constexpr (EPI != EPI_F32) {
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      const int64_t n = ncol0 + j * 16;
+      bias4[j] = (p.bias && n < p.N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FM; i++) {
     const int64_t m = m_base + i * 16 + frow;
     if (m >= p.M) continue;
+    // row base pointers, computed once per row
+    float* c32 = (float*)p.C + m * p.ldc + ncol0;
+    bf16_t* c16 = (bf16_t*)p.C + m * p.ldc + ncol0;
+    float* wsp = p.ws + ((int64_t)slice * p.M + m) * p.N + ncol0;
+    const bf16_t* resp = p.res ? p.res + m * p.ldr + ncol0 : nullptr;
+    const bf16_t* auxi = p.aux_in ? p.aux_in + m * p.ldaux + ncol0 : nullptr;
+    bf16_t* auxo = p.aux_out ? p.aux_out + m * p.ldaux + ncol0 : nullptr;
 #pragma unroll
     for (int j = 0; j < FN; j++) {
-      const int64_t n = n_base + j * 16 + fg * 4;
-      if (n >= p.N) continue;  // N % 4 == 0 is enforced by the host wrapper
+      if (ncol0 + j * 16 >= p.N) continue;  // N % 4 == 0 is enforced by the host wrapper
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if constexpr (EPI == EPI_F32) {
         if (p.splitk > 1) {  // raw partial; alpha/beta are applied by the slice reduction
-          *(float4*)(p.ws + ((int64_t)slice * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)(wsp + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
           continue;
         }
-        float* cp = (float*)p.C + m * p.ldc + n;
         float4 o = make_float4(v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha);
         if (p.beta != 0.f) {
-          const float4 c0 = *(const float4*)cp;
+          const float4 c0 = *(const float4*)(c32 + j * 16);
           o.x += p.beta * c0.x;
           o.y += p.beta * c0.y;
           o.z += p.beta * c0.z;
           o.w += p.beta * c0.w;
         }
-        *(float4*)cp = o;
+        *(float4*)(c32 + j * 16) = o;
       } else {
-        if (p.bias) {
-          const float4 b4 = *(const float4*)(p.bias + n);
-          v[0] += b4.x;
-          v[1] += b4.y;
-          v[2] += b4.z;
-          v[3] += b4.w;
-        }
+        v[0] += bias4[j].x;
+        v[1] += bias4[j].y;
+        v[2] += bias4[j].z;
+        v[3] += bias4[j].w;
         if constexpr (EPI == EPI_GELU) {
           u32x2_t u;
           u[0] = pack_bf2(v[0], v[1]);
           u[1] = pack_bf2(v[2], v[3]);
-          if (p.aux_out) *(u32x2_t*)(p.aux_out + m * p.ldaux + n) = u;
+          if (auxo) *(u32x2_t*)(auxo + j * 16) = u;
           // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
           v[0] = gelu_f(bf_lo(u[0]));
           v[1] = gelu_f(bf_hi(u[0]));
           v[2] = gelu_f(bf_lo(u[1]));
           v[3] = gelu_f(bf_hi(u[1]));
         } else if constexpr (EPI == EPI_DGELU) {
-          const u32x2_t u = *(const u32x2_t*)(p.aux_in + m * p.ldaux + n);
+          const u32x2_t u = *(const u32x2_t*)(auxi + j * 16);
           v[0] *= dgelu_f(bf_lo(u[0]));
           v[1] *= dgelu_f(bf_hi(u[0]));
           v[2] *= dgelu_f(bf_lo(u[1]));
           v[3] *= dgelu_f(bf_hi(u[1]));
         } else {
-          if (p.res) {
-            const u32x2_t r2 = *(const u32x2_t*)(p.res + m * p.ldr + n);
+          if (resp) {
+            const u32x2_t r2 = *(const u32x2_t*)(resp + j * 16);
             v[0] += bf_lo(r2[0]);
             v[1] += bf_hi(r2[0]);
             v[2] += bf_lo(r2[1]);
@@ -86,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
         u32x2_t o;
         o[0] = pack_bf2(v[0], v[1]);
         o[1] = pack_bf2(v[2], v[3]);
-        *(u32x2_t*)((bf16_t*)p.C + m * p.ldc + n) = o;
+        *(u32x2_t*)(c16 + j * 16) = o;
       }
     }
   }

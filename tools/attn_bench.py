@@ -19,8 +19,11 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only-fwd", action="store_true")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--fwd-qt", type=int, default=2)
     args = ap.parse_args()
     dev = "cuda"
+    from jepa_amd.hip.lib import load_library
+    load_library().vj_attn_set_variant(args.fwd_qt)
     g = torch.Generator(device=dev).manual_seed(0)
     for tag, B, S, H, hd in SHAPES:
         if args.shapes and tag.split()[0] not in args.shapes:
