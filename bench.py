@@ -209,8 +209,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, n_total):
         last = run(i)
+    host_enqueue = time.perf_counter() - t0
     sync()
     elapsed = time.perf_counter() - t0
+    log(f"host enqueue time {1e3 * host_enqueue / args.steps:.1f} ms/step (GPU step {1e3 * elapsed / args.steps:.1f} ms)")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -17,8 +17,17 @@ I64 = torch.int64
 EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32 = 0, 1, 2, 3
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream   # C accessor: ~20x cheaper than torch.cuda.current_stream()
+_dev_index = None
+
+
 def _stream(stream=None):
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream if stream is None else stream)
+    global _dev_index
+    if stream is not None:
+        return ctypes.c_void_p(stream)
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()   # one process per GPU: the device never changes afterwards
+    return ctypes.c_void_p(_raw_stream(_dev_index))
 
 
 def _ptr(t):
@@ -292,12 +301,13 @@ def pred_assemble(e, mask_token, pos, idx_e, idx_p, out=None, stream=None):
     return out
 
 
-def target_rows(x, gamma, beta, idx, B, N, eps_norm, eps_ln=1e-5, stream=None):
+def target_rows(x, gamma, beta, idx, B, N, eps_norm, eps_ln=1e-5, out=None, stream=None):
     lib = load_library()
     _req(x, BF16, "x")
+    idx = _req(idx, I64, "idx")
     K = idx.shape[1]
     D = x.shape[-1]
-    h = torch.empty((B, K, D), dtype=F32, device=x.device)
+    h = torch.empty((B, K, D), dtype=F32, device=x.device) if out is None else out
     check(lib.vj_target_rows(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(idx), _ptr(h), B, N, K, D, eps_norm, eps_ln,
                              _stream(stream)), "vj_target_rows")
     return h
