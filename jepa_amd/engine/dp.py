@@ -19,8 +19,11 @@ import torch.distributed as dist
 class GradReducer:
     def __init__(self, arena, vit, pred, world_size, overlap=True, pred_layers_per_bucket=4):
         self.arena = arena
+        import os
         self.world = world_size
-        self.enabled = world_size > 1
+        # VJ_FORCE_DP=1 exercises the bucket / stream / event path with a 1-rank RCCL communicator (single-GPU boxes)
+        self.enabled = world_size > 1 or (os.environ.get("VJ_FORCE_DP", "0") == "1" and dist.is_available()
+                                          and dist.is_initialized())
         self.overlap = overlap
         self.buckets = {}      # (kind, layer) -> list of (lo, hi) ranges of arena.G that become final at that hook
         self.tail = []
@@ -57,20 +60,23 @@ class GradReducer:
         if pos < total:
             self.tail.append((pos, total))
 
-    def begin(self):
+    def begin(self, producer_stream=None):
+        """producer_stream: the HIP stream on which the per-layer weight gradients are enqueued (the engine's side
+        stream); bucket launches wait on IT, so the main (dgrad) stream never stalls on a collective."""
         if not self.enabled:
             return
         self.launched = []
         self._pending = []
+        self._producer = producer_stream
         if self.arena.G.is_cuda and self.overlap and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=self.arena.G.device)
 
-    def _reduce(self, lo, hi):
+    def _reduce(self, lo, hi, producer=None):
         g = self.arena.G[lo:hi]
         self.launched.append((lo, hi))
         if g.is_cuda and self.overlap:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            ev.record(producer if producer is not None else torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
@@ -81,7 +87,7 @@ class GradReducer:
         if not self.enabled:
             return
         for lo, hi in self.buckets.get((kind, layer), ()):
-            self._reduce(lo, hi)
+            self._reduce(lo, hi, getattr(self, "_producer", None))
 
     def finish(self):
         """Reduce the tail bucket and make the compute stream wait for every outstanding bucket."""

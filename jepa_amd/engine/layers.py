@@ -174,8 +174,7 @@ def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_don
         dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha)
         saved_blocks[li] = None
         if on_layer_done is not None:
-            side_stream(dout.device).join()   # this layer's wgrads must be complete before its bucket goes out
-            on_layer_done("enc", li)
+            on_layer_done("enc", li)          # bucket launch waits on the side stream's event, not on this stream
     _linear_backward(dx, tok, ew.patch, alpha, need_dx=False)
     side_stream(dout.device).join()
     if on_layer_done is not None:
@@ -229,13 +228,11 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
     for sg, psg, tsg in zip(enc_segs, segs, tsegs):
         ops.copy_rows(_rows(dt, tsg), _rows(dx, psg), psg.B, tsg.S, 0, psg.S, sg.S, tsg.S, Dp)
     if on_layer_done is not None:
-        side_stream(dzhat.device).join()
         on_layer_done("pred", len(pw.blocks))
     for li in range(len(pw.blocks) - 1, -1, -1):
         dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha)
         saved_blocks[li] = None
         if on_layer_done is not None:
-            side_stream(dzhat.device).join()
             on_layer_done("pred", li)
     # token assembly backward: mask-token grads = sum of the target rows; context rows flow to predictor_embed
     de = torch.empty(e_shape, dtype=torch.bfloat16, device=dzhat.device)

@@ -192,7 +192,8 @@ class Trainer:
             ops.token_pstd(zi, pstd, B, t.S, D, accumulate=i > 0)
         ops.reg_finish(pstd, n_masks, self._stat[1:2])
         # ---- backward (predictor first, then encoder layers 23..0); gradient buckets go out as layers finish
-        self.reducer.begin()
+        side = side_stream(self.device)
+        self.reducer.begin(side.stream if side.enabled else None)
         hook = self.reducer.layer_done if self.reducer.enabled else None
         dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=hook)
         encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=hook)
