@@ -249,9 +249,21 @@ def main():
         g = fam["gemm_nt"]
         ach = g["flop"] / (g["ms"] * 1e-3)
         log(f"roofline pass: {json.dumps({k: dict(v, tflops=round(v['flop'] / v['ms'] / 1e9, 1)) for k, v in fam.items()})}")
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<64,*> (bf16 MFMA 16x16x32, LDS-DMA staged)",
+        # HBM bytes per launch of the dominant kernel: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+        # correction + WRITE_SIZE), committed under profiles/ -- counters cannot be collected from inside this process
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_hbm_pmc.json")
+        if os.path.exists(pmc) and args.workload == "vitl16":
+            with open(pmc) as fjs:
+                ent = json.load(fjs).get("gemm_nt_8phase_kernel<0>")
+            if ent:
+                traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r01_c_hbm_pmc.md"
+        roof = {"bound": "mfma",
+                "kernel": "bf16 MFMA GEMM family (gemm_nt_8phase_kernel 256x256 staggered 8-phase + gemm_nt_kernel "
+                          "128x128 split-K wgrads; MFMA 16x16x32, LDS-DMA staged)",
                 "achieved": round(ach / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_BF16_PEAK, 4), "traffic": None,
+                "frac": round(ach / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+                "traffic_source": traffic_src,
                 "launches_per_step": g["launches"] // n_inst,
                 "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
                 "gemm_ms_per_step": round(g["ms"] / n_inst, 2),
