@@ -43,6 +43,15 @@ struct RowTile {
   // base: pointer to element [row 0][col 0] of this (b,h) slice; rs: row stride in elements
   static __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int64_t rs, int r0, int nrows, int hd,
                                               int tid, u32x4_t* regs) {
+    if (r0 + 64 <= nrows && hd == HDP && (64 * CHP) % NT == 0) {   // wave-uniform fast path: no per-item predicates
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int item = tid + it * NT;
+        const int row = item / CHP, ch = item % CHP;
+        regs[it] = *(const u32x4_t*)(base + (int64_t)(r0 + row) * rs + ch * 8);
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int item = tid + it * NT;
@@ -392,12 +401,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
         sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc, 0, 0, 0);
         dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc, 0, 0, 0);
       }
+      const float4 lse4 = *(const float4*)(lse_s + qt * 16 + 4 * g);   // queries qt*16 + 4g + {0..3}
+      const float4 dl4 = *(const float4*)(dl_s + qt * 16 + 4 * g);
+      const float lse_a[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dl_a[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int q = qt * 16 + 4 * g + r;
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -lse_s[q]));  // padded queries: lse = +inf -> 0
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -lse_a[r]));  // padded queries: lse = +inf -> 0
         pv[qt][r] = p;
-        dsv[qt][r] = p * (dpacc[r] - dl_s[q]);
+        dsv[qt][r] = p * (dpacc[r] - dl_a[r]);
       }
     }
 #pragma unroll
