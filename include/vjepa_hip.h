@@ -129,8 +129,11 @@ int vj_latent_loss(const void* z_bf16, const float* h, void* dz_bf16, int64_t nu
                    float out_scale, int accumulate, float* loss_out, void* ws, int64_t ws_bytes,
                    vj_stream_t stream);
 /* reg_fn (train.py:448-449,458): pstd[b,d] (+)= sqrt(var_k z[b,k,d] + 1e-4); reg = mean(relu(1 - pstd/n_masks)) */
-int vj_token_pstd(const void* z_bf16, float* pstd, int64_t B, int64_t K, int64_t D, int accumulate,
-                  vj_stream_t stream);
+int vj_token_pstd(const void* z_bf16, float* pstd, float* stats /* nullable [B,D,2] = {mean, sqrt(var+eps)} */,
+                  int64_t B, int64_t K, int64_t D, int accumulate, vj_stream_t stream);
+/* backward of the regulariser: dz -= coef * 1[pstd_sum/n_masks < 1] * (z - mean) / ((K-1) * sqrt(var+eps)) */
+int vj_reg_grad(const void* z_bf16, const float* pstd_sum, const float* stats, void* dz_bf16, int64_t B, int64_t K,
+                int64_t D, int64_t n_masks, float coef, vj_stream_t stream);
 int vj_reg_finish(const float* pstd_sum, int64_t n, int64_t n_masks, float* out, vj_stream_t stream);
 
 /* ---- parameter update over flat fp32 arenas (train.py:461-487; app/vjepa/utils.py:156-210) -------------------

@@ -401,7 +401,8 @@ extern "C" int vj_latent_loss(const void* z_bf16, const float* h, void* dz_bf16,
 // one workgroup per (b, 64-column slab): 4 waves split the K rows, each lane owns one column pair... 8 columns per
 // thread (16-byte loads), shifted single-pass sums (shift = first row) combined across the 8 row-lanes in LDS.
 __global__ __launch_bounds__(256) void token_pstd_kernel(const bf16_t* __restrict__ z, float* __restrict__ pstd,
-                                                         int64_t K, int D, int accumulate) {
+                                                         float* __restrict__ stats, int64_t K, int D,
+                                                         int accumulate) {
   __shared__ float red[2][32][65];
   const int64_t b = blockIdx.y;
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;       // 8 column groups of 8, 32 row lanes
@@ -441,6 +442,10 @@ __global__ __launch_bounds__(256) void token_pstd_kernel(const bf16_t* __restric
       const float v = sqrtf(fmaxf(var, 0.f) + 1e-4f);
       float* o = pstd + b * D + d;
       *o = accumulate ? (*o + v) : v;
+      if (stats) {   // per-(b,d) token mean and sqrt(var + eps) of THIS mask, for reg_grad
+        stats[(b * D + d) * 2] = bf2f(zp[d]) + ss / (float)K;
+        stats[(b * D + d) * 2 + 1] = v;
+      }
     }
   }
 }
@@ -457,13 +462,13 @@ __global__ __launch_bounds__(256) void reg_finish_kernel(const float* __restrict
   if (threadIdx.x == 0) *out = (red[0] + red[1] + red[2] + red[3]) / (float)n;
 }
 
-extern "C" int vj_token_pstd(const void* z_bf16, float* pstd, int64_t B, int64_t K, int64_t D, int accumulate,
-                             hipStream_t stream) {
+extern "C" int vj_token_pstd(const void* z_bf16, float* pstd, float* stats, int64_t B, int64_t K, int64_t D,
+                             int accumulate, hipStream_t stream) {
   VJ_CHECK_ARG(K >= 2, "vj_token_pstd: need at least 2 tokens for an unbiased variance (K=%ld)", (long)K);
   if (B * D == 0) return 0;
   VJ_CHECK_ARG(D % 8 == 0, "vj_token_pstd: D must be a multiple of 8");
   hipLaunchKernelGGL(token_pstd_kernel, dim3((unsigned)cdiv64(D, 64), (unsigned)B), dim3(256), 0, stream,
-                     (const bf16_t*)z_bf16, pstd, K, (int)D, accumulate);
+                     (const bf16_t*)z_bf16, pstd, stats, K, (int)D, accumulate);
   VJ_LAUNCH_CHECK("vj_token_pstd");
   return 0;
 }
@@ -471,5 +476,43 @@ extern "C" int vj_token_pstd(const void* z_bf16, float* pstd, int64_t B, int64_t
 extern "C" int vj_reg_finish(const float* pstd_sum, int64_t n, int64_t n_masks, float* out, hipStream_t stream) {
   hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(256), 0, stream, pstd_sum, n, 1.0f / (float)n_masks, out);
   VJ_LAUNCH_CHECK("vj_reg_finish");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reg_grad: dz[b,k,d] += coef * d/dz mean_{b,d} relu(1 - pstd_avg[b,d]),  pstd_avg = pstd_sum / n_masks
+//   = -coef / (B*D*n_masks) * 1[pstd_avg < 1] * (z - mean) / ((K-1) * sqrt(var + eps))       (train.py:448-459)
+// dz holds the latent-loss gradient in units of 1/gscale (see vj_latent_loss); `coef` is pre-divided accordingly.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reg_grad_kernel(const bf16_t* __restrict__ z, const float* __restrict__ pstd_sum,
+                                                       const float* __restrict__ stats, bf16_t* __restrict__ dz,
+                                                       int64_t B, int64_t K, int D, float inv_masks, float coef) {
+  const int64_t n8 = B * K * D / 8;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n8; q += (int64_t)gridDim.x * 256) {
+    const int64_t e = q * 8;
+    const int d0 = (int)(e % D);
+    const int64_t b = e / ((int64_t)K * D);
+    float zv[8], gv[8];
+    load8(z + e, zv);
+    load8(dz + e, gv);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int64_t bd = b * D + d0 + j;
+      const float active = (pstd_sum[bd] * inv_masks < 1.0f) ? 1.0f : 0.f;
+      gv[j] -= coef * active * (zv[j] - stats[bd * 2]) / ((float)(K - 1) * stats[bd * 2 + 1]);
+    }
+    store8(dz + e, gv);
+  }
+}
+
+extern "C" int vj_reg_grad(const void* z_bf16, const float* pstd_sum, const float* stats, void* dz_bf16, int64_t B,
+                           int64_t K, int64_t D, int64_t n_masks, float coef, hipStream_t stream) {
+  VJ_CHECK_ARG(D % 8 == 0 && K >= 2, "vj_reg_grad: need D %% 8 == 0 and K >= 2");
+  if (B * K * D == 0) return 0;
+  int64_t g = cdiv64(B * K * D / 8, 256);
+  if (g > 256 * 8) g = 256 * 8;
+  hipLaunchKernelGGL(reg_grad_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const bf16_t*)z_bf16, pstd_sum, stats,
+                     (bf16_t*)dz_bf16, B, K, (int)D, 1.0f / (float)n_masks, coef);
+  VJ_LAUNCH_CHECK("vj_reg_grad");
   return 0;
 }

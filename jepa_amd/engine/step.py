@@ -87,9 +87,6 @@ def _strip(name):
 class Trainer:
     def __init__(self, encoder, predictor, target_encoder, loss_exp=1.0, reg_coeff=0.0, betas=(0.9, 0.999),
                  eps=1e-8, clip_grad=None, device=None, world_size=1, overlap_comm=True, check_finite=False):
-        if reg_coeff != 0.0:
-            raise NotImplementedError("reg_coeff != 0: the variance regulariser is computed and logged, but its "
-                                      "backward is not implemented (every shipped V-JEPA config uses 0.0)")
         self.encoder, self.predictor, self.target_encoder = encoder, predictor, target_encoder
         self.vit, self.pred, self.tvit = encoder.backbone, predictor.backbone, target_encoder.backbone
         self.device = torch.device(device) if device is not None else next(encoder.parameters()).device
@@ -185,12 +182,19 @@ class Trainer:
         alpha = 1.0 / (nmin * n_masks)
         dzhat = torch.empty_like(zhat)
         pstd = torch.empty((B, D), dtype=torch.float32, device=self.device)
+        with_reg = self.reg_coeff != 0.0
+        stats = [torch.empty((B, D, 2), dtype=torch.float32, device=self.device) if with_reg else None for _ in tsegs]
         for i, t in enumerate(tsegs):
             zi = zhat[t.row0:t.row0 + t.rows]
             ops.latent_loss(zi, h[i], self._stat[0:1], p=self.loss_exp, out_scale=1.0 / (numels[i] * n_masks),
                             accumulate=i > 0, dz=dzhat[t.row0:t.row0 + t.rows], gscale=nmin / numels[i])
-            ops.token_pstd(zi, pstd, B, t.S, D, accumulate=i > 0)
+            ops.token_pstd(zi, pstd, B, t.S, D, accumulate=i > 0, stats=stats[i])
         ops.reg_finish(pstd, n_masks, self._stat[1:2])
+        if with_reg:   # gradient of reg_coeff * mean(relu(1 - pstd)), expressed in the 1/alpha units dzhat carries
+            coef = self.reg_coeff / (B * D * n_masks) / alpha
+            for i, t in enumerate(tsegs):
+                ops.reg_grad(zhat[t.row0:t.row0 + t.rows], pstd, stats[i], dzhat[t.row0:t.row0 + t.rows], B, t.S, D,
+                             n_masks, coef)
         # ---- backward (predictor first, then encoder layers 23..0); gradient buckets go out as layers finish
         side = side_stream(self.device)
         self.reducer.begin(side.stream if side.enabled else None)

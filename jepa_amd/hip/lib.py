@@ -47,7 +47,8 @@ SIGNATURES = {
     "vj_target_rows": (I32, [P, P, P, P, P, I64, I64, I64, I64, F32, F32, P]),
     "vj_latent_loss_ws_bytes": (I64, []),
     "vj_latent_loss": (I32, [P, P, P, I64, F32, F32, F32, I32, P, P, I64, P]),
-    "vj_token_pstd": (I32, [P, P, I64, I64, I64, I32, P]),
+    "vj_token_pstd": (I32, [P, P, P, I64, I64, I64, I32, P]),
+    "vj_reg_grad": (I32, [P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vj_reg_finish": (I32, [P, I64, I64, P, P]),
     "vj_adamw_ema": (I32, [P, P, P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, F32, P]),
     "vj_ema_update": (I32, [P, P, P, I64, F32, P]),

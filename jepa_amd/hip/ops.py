@@ -324,9 +324,16 @@ def latent_loss(z, h, loss_out, p=1.0, out_scale=1.0, accumulate=False, dz=None,
     return loss_out
 
 
-def token_pstd(z, pstd, B, K, D, accumulate, stream=None):
+def token_pstd(z, pstd, B, K, D, accumulate, stats=None, stream=None):
     lib = load_library()
-    check(lib.vj_token_pstd(_ptr(z), _ptr(pstd), B, K, D, int(accumulate), _stream(stream)), "vj_token_pstd")
+    check(lib.vj_token_pstd(_ptr(z), _ptr(pstd), _ptr(stats), B, K, D, int(accumulate), _stream(stream)),
+          "vj_token_pstd")
+
+
+def reg_grad(z, pstd_sum, stats, dz, B, K, D, n_masks, coef, stream=None):
+    lib = load_library()
+    check(lib.vj_reg_grad(_ptr(z), _ptr(pstd_sum), _ptr(stats), _ptr(dz), B, K, D, n_masks, coef, _stream(stream)),
+          "vj_reg_grad")
 
 
 def reg_finish(pstd, n_masks, out, stream=None):

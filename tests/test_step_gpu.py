@@ -206,3 +206,38 @@ def test_vit_tiny_step_vs_oracle():
     assert rel_l2(w, state["enc"]["blocks.0.mlp.fc1.weight"]) < 5e-3
     wt = tr.tarena.f32("enc.blocks.0.mlp.fc1.weight").cpu()
     assert rel_l2(wt, state["tgt"]["blocks.0.mlp.fc1.weight"]) < 1e-4
+
+
+def test_variance_regulariser_backward_vs_oracle():
+    """reg_coeff != 0 (train.py:448-459): loss and gradients of loss_jepa + reg_coeff * mean(relu(1 - pstd))."""
+    import copy
+    from oracle import vjepa_oracle as O
+    from jepa_amd.engine.step import Trainer
+    z = load_micro()
+    enc_w, pred_w = micro_weights(z)
+    # scale the predictor's output projection down so the token std is < 1 and the relu is active everywhere
+    pred_w["predictor_proj.weight"] = pred_w["predictor_proj.weight"] * 0.25
+    enc, pred = build_micro_modules()
+    load_into(enc, enc_w)
+    load_into(pred, pred_w)
+    tgt = copy.deepcopy(enc)
+    for p in tgt.parameters():
+        p.requires_grad = False
+    enc.to(DEV), pred.to(DEV), tgt.to(DEV)
+    hp = dict(HP, reg_coeff=0.5)
+    tr = Trainer(enc, pred, tgt, loss_exp=hp["loss_exp"], reg_coeff=hp["reg_coeff"], betas=hp["betas"], eps=hp["eps"],
+                 device=DEV)
+    clips, me, mp = step_inputs(z, 0)
+    state = dict(enc={k: v.clone() for k, v in enc_w.items()}, pred={k: v.clone() for k, v in pred_w.items()},
+                 tgt={k: v.clone() for k, v in enc_w.items()}, opt={})
+    ref = O.train_step(state, clips, me, mp, MICRO, hp, 1)
+    out = tr.train_step(clips.to(DEV), [m.to(DEV) for m in me], [m.to(DEV) for m in mp], lr=ref["lr"], wd=ref["wd"],
+                        ema=ref["ema"])
+    assert ref["loss_reg"] > 0.05, "test setup: the regulariser must be active"
+    assert abs(out.loss_reg - ref["loss_reg"]) < 2e-2 * ref["loss_reg"], (out.loss_reg, ref["loss_reg"])
+    assert abs(out.loss - ref["loss"]) < 2e-3 * abs(ref["loss"]), (out.loss, ref["loss"])
+    for name in ("predictor_proj.weight", "predictor_blocks.1.mlp.fc1.weight", "mask_tokens.0"):
+        g = tr.arena.grad("pred." + name).float().cpu().reshape(ref["grads"]["pred"][name].shape)
+        assert rel_l2(g, ref["grads"]["pred"][name]) < 8e-2, (name, rel_l2(g, ref["grads"]["pred"][name]))
+    g = tr.arena.grad("enc.blocks.0.attn.qkv.weight").float().cpu()
+    assert cosine(g, ref["grads"]["enc"]["blocks.0.attn.qkv.weight"]) > 0.995
