@@ -241,3 +241,83 @@ def test_variance_regulariser_backward_vs_oracle():
         assert rel_l2(g, ref["grads"]["pred"][name]) < 8e-2, (name, rel_l2(g, ref["grads"]["pred"][name]))
     g = tr.arena.grad("enc.blocks.0.attn.qkv.weight").float().cpu()
     assert cosine(g, ref["grads"]["enc"]["blocks.0.attn.qkv.weight"]) > 0.995
+
+
+def _oracle_state(enc, pred):
+    ow_enc = {k[len("backbone."):]: v.detach().clone() for k, v in enc.state_dict().items()}
+    ow_pred = {k[len("backbone."):]: v.detach().clone() for k, v in pred.state_dict().items()}
+    return dict(enc=ow_enc, pred=ow_pred, tgt={k: v.clone() for k, v in ow_enc.items()}, opt={})
+
+
+def test_vit_tiny_loss_curve_12_steps_vs_oracle():
+    """Per-step loss curve over 12 optimisation steps (same init, clips, masks, schedules): every step within
+    1e-3 relative of the fp32 oracle, i.e. the bf16 HIP trajectory does not drift away from the reference one."""
+    import copy
+    from oracle import vjepa_oracle as O
+    from jepa_amd.app.vjepa.utils import init_video_model
+    from jepa_amd.engine.step import Trainer
+    torch.manual_seed(0)
+    enc, pred = init_video_model(device="cpu", patch_size=16, num_frames=8, tubelet_size=2, model_name="vit_tiny",
+                                 crop_size=64, pred_depth=2, pred_embed_dim=96, uniform_power=True,
+                                 use_mask_tokens=True, num_mask_tokens=2, zero_init_mask_tokens=True)
+    cfg = dict(embed_dim=192, depth=12, heads=3, pred_dim=96, pred_depth=2, num_mask_tokens=2, patch=16, tubelet=2,
+               num_patches=64)
+    state = _oracle_state(enc, pred)
+    tgt = copy.deepcopy(enc)
+    for p in tgt.parameters():
+        p.requires_grad = False
+    enc.to(DEV), pred.to(DEV), tgt.to(DEV)
+    tr = Trainer(enc, pred, tgt, device=DEV)
+    masks_cfg = [dict(aspect_ratio=(0.75, 1.5), num_blocks=4, spatial_scale=(0.15, 0.15), temporal_scale=(1.0, 1.0)),
+                 dict(aspect_ratio=(0.75, 1.5), num_blocks=1, spatial_scale=(0.6, 0.6), temporal_scale=(0.5, 1.0))]
+    gens = O.make_mask_gens(masks_cfg, 64, 8, 16, 2)
+    hp = dict(HP, ipe=20, warmup=0.25)
+    worst = 0.0
+    for step in range(1, 13):
+        clips = torch.randn(4, 3, 8, 64, 64, generator=torch.Generator().manual_seed(77 + step))
+        torch.manual_seed(999 + step)
+        me, mp = zip(*[gq(4) for gq in gens])
+        ref = O.train_step(state, clips, list(me), list(mp), cfg, hp, step)
+        out = tr.train_step(clips.to(DEV), [m.to(DEV) for m in me], [m.to(DEV) for m in mp], lr=ref["lr"],
+                            wd=ref["wd"], ema=ref["ema"])
+        rel = abs(out.loss - ref["loss"]) / abs(ref["loss"])
+        worst = max(worst, rel)
+        assert rel < 1e-3, (step, out.loss, ref["loss"])
+    print(f"worst relative loss deviation over 12 steps: {worst:.2e}")
+
+
+def test_vit_large_step_vs_oracle_baseline_shape():
+    """BASELINE configs[1] model and clip shape (ViT-L/16, 16x224x224, vitl16.yaml masks) at B=2: first-step loss
+    within 1e-3 relative of the fp32 oracle, mask tokens' gradient direction preserved."""
+    import copy
+    from oracle import vjepa_oracle as O
+    from jepa_amd.app.vjepa.utils import init_video_model
+    from jepa_amd.engine.step import Trainer
+    torch.manual_seed(0)
+    enc, pred = init_video_model(device="cpu", patch_size=16, num_frames=16, tubelet_size=2, model_name="vit_large",
+                                 crop_size=224, pred_depth=12, pred_embed_dim=384, uniform_power=True,
+                                 use_mask_tokens=True, num_mask_tokens=2, zero_init_mask_tokens=True)
+    cfg = dict(embed_dim=1024, depth=24, heads=16, pred_dim=384, pred_depth=12, num_mask_tokens=2, patch=16,
+               tubelet=2, num_patches=1568)
+    state = _oracle_state(enc, pred)
+    tgt = copy.deepcopy(enc)
+    for p in tgt.parameters():
+        p.requires_grad = False
+    enc.to(DEV), pred.to(DEV), tgt.to(DEV)
+    tr = Trainer(enc, pred, tgt, device=DEV)
+    masks_cfg = [dict(aspect_ratio=(0.75, 1.5), num_blocks=8, spatial_scale=(0.15, 0.15), temporal_scale=(1.0, 1.0)),
+                 dict(aspect_ratio=(0.75, 1.5), num_blocks=2, spatial_scale=(0.7, 0.7), temporal_scale=(1.0, 1.0))]
+    gens = O.make_mask_gens(masks_cfg, 224, 16, 16, 2)
+    clips = torch.randn(2, 3, 16, 224, 224, generator=torch.Generator().manual_seed(1234))
+    torch.manual_seed(4321)
+    me, mp = zip(*[g(2) for g in gens])
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    ref = O.train_step(state, clips, list(me), list(mp), cfg, dict(HP), 1)
+    out = tr.train_step(clips.to(DEV), [m.to(DEV) for m in me], [m.to(DEV) for m in mp], lr=ref["lr"], wd=ref["wd"],
+                        ema=ref["ema"])
+    assert abs(out.loss - ref["loss"]) < 1e-3 * abs(ref["loss"]), (out.loss, ref["loss"])
+    g = tr.arena.grad("pred.mask_tokens.1").float().cpu().reshape(-1)
+    assert cosine(g, ref["grads"]["pred"]["mask_tokens.1"].reshape(-1)) > 0.99
+    g = tr.arena.grad("enc.blocks.23.mlp.fc2.bias").float().cpu()
+    assert cosine(g, ref["grads"]["enc"]["blocks.23.mlp.fc2.bias"]) > 0.99
+    print(f"ViT-L first-step loss: HIP {out.loss:.6f} vs oracle {ref['loss']:.6f}")
