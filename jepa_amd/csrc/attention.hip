@@ -19,12 +19,37 @@
 // Softmax is computed in base 2: s2 = (q.k) * scale * log2(e); lse2 = max2 + log2(sum) is what the forward
 // saves for the backward (an internal format, produced and consumed only here).
 #include "common.hpp"
+#include <type_traits>
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
   bf2_t v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
+}
+
+// 16 bytes per lane, global -> LDS, asynchronous (vmcnt).  Issued through inline assembly on purpose: the compiler
+// then does not know that LDS is written behind its back and inserts no conservative `s_waitcnt vmcnt(0)` in front of
+// later LDS reads (it does so for ds_read_b64_tr_b16 after the builtin form, which would collapse the prefetch
+// distance); completion is tracked by hand with wait_vmcnt<N>() + raw_barrier().  lds_base must be wave-uniform: the
+// hardware adds lane * 16.
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(gsrc) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void raw_barrier() {   // s_barrier without the vmcnt(0) drain of __syncthreads()
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only: this wave's LDS reads of the previous tile are complete
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 #define DEFER_LOG2 5.0f  // forward softmax: rescale O only when a row max grows by more than 2^5
@@ -40,16 +65,22 @@ struct RowTile {
   static constexpr int CHP = HDP / 8;
   static constexpr int NIT = (64 * CHP + NT - 1) / NT;
   static constexpr int BYTES = 64 * HDP * 2;
+  static constexpr bool CAN_FULL = (64 * CHP) % NT == 0;
+  // 64 complete rows with the full head dimension: no predicates at all
+  static __device__ __forceinline__ void load_full(const bf16_t* __restrict__ base, int64_t rs, int r0, int tid,
+                                                   u32x4_t* regs) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int item = tid + it * NT;
+      const int row = item / CHP, ch = item % CHP;
+      regs[it] = *(const u32x4_t*)(base + (int64_t)(r0 + row) * rs + ch * 8);
+    }
+  }
   // base: pointer to element [row 0][col 0] of this (b,h) slice; rs: row stride in elements
   static __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int64_t rs, int r0, int nrows, int hd,
                                               int tid, u32x4_t* regs) {
-    if (r0 + 64 <= nrows && hd == HDP && (64 * CHP) % NT == 0) {   // wave-uniform fast path: no per-item predicates
-#pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int item = tid + it * NT;
-        const int row = item / CHP, ch = item % CHP;
-        regs[it] = *(const u32x4_t*)(base + (int64_t)(r0 + row) * rs + ch * 8);
-      }
+    if (r0 + 64 <= nrows && hd == HDP && CAN_FULL) {   // wave-uniform fast path: no per-item predicates
+      load_full(base, rs, r0, tid, regs);
       return;
     }
 #pragma unroll
@@ -127,7 +158,12 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
                                                        float sc, int nqb) {
   constexpr int NT = 8 * 64 / QT;   // 128 queries per workgroup, 16*QT per wave
   using RT = RowTile<HDP, NT>;
-  __shared__ __attribute__((aligned(16))) char smem[4 * RT::BYTES];   // {K,V} x 2 buffers
+  // {K,V} x NBUF buffers, filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write): the DMA
+  // destination is lane-linear, so the XOR swizzle of the row-major image is applied on the per-lane SOURCE chunk.
+  constexpr int NBUF = HDP <= 64 ? 3 : 2, DIST = NBUF - 1;   // prefetch distance in tiles
+  static_assert(RT::CAN_FULL || NT == 512, "tile items must be a multiple of the workgroup size");
+  constexpr int NDMA = RT::CAN_FULL ? RT::NIT : 1;            // DMA instructions per wave per K (or V) tile
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * RT::BYTES];
   const TrFrag<HDP> trf(threadIdx.x & 63);
   constexpr int KS = HDP / 32, DT = HDP / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -162,33 +198,70 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
     lrun[qt] = 0.f;
   }
 
-  u32x4_t kreg[RT::NIT], vreg[RT::NIT];
   const int nt = (S + 63) / 64;
-  // double-buffered LDS image, ONE barrier per tile: tile t+1 is written into the other buffer right after the
-  // barrier of tile t (its global loads were issued a whole tile earlier), tile t+2's loads are issued next.
-  RT::load(kbase, rs, 0, S, hd, tid, kreg);
-  RT::load(vbase, rs, 0, S, hd, tid, vreg);
-  RT::store(smem, tid, kreg);
-  RT::store(smem + RT::BYTES, tid, vreg);
-  if (nt > 1) {
-    RT::load(kbase, rs, 64, S, hd, tid, kreg);
-    RT::load(vbase, rs, 64, S, hd, tid, vreg);
+  // per-lane source of DMA item it: row (item / CHP) of the tile, chunk (item % CHP) ^ swizzle(row); chunks beyond
+  // the real head dimension re-read chunk 0 (they only meet zero Q chunks / produce discarded O columns) and rows
+  // beyond S re-read row S-1 (their scores are masked to -inf, P = 0): the DMA never needs a zero fill.
+  int dma_row[NDMA], dma_off[NDMA];
+  const bool dma_on = RT::CAN_FULL || tid < 64 * RT::CHP;
+#pragma unroll
+  for (int it = 0; it < NDMA; it++) {
+    const int item = RT::CAN_FULL ? tid + it * NT : (tid < 64 * RT::CHP ? tid : 0);
+    const int row = item / RT::CHP, c = (item % RT::CHP) ^ rm_swz<HDP>(row);
+    const int col = c * 8 < hd ? c * 8 : 0;
+    dma_row[it] = row;
+    dma_off[it] = row * (int)rs + col;
   }
-
-  for (int t = 0; t < nt; t++) {
-    const int k0 = t * 64;
-    char* k_lds = smem + (t & 1) * (2 * RT::BYTES);
-    char* v_lds = k_lds + RT::BYTES;
-    __syncthreads();  // tile t is in LDS for every wave; every wave is done reading tile t-1 (the other buffer)
-    if (t + 1 < nt) {
-      char* kn = smem + ((t + 1) & 1) * (2 * RT::BYTES);
-      RT::store(kn, tid, kreg);
-      RT::store(kn + RT::BYTES, tid, vreg);
-      if (t + 2 < nt) {
-        RT::load(kbase, rs, k0 + 128, S, hd, tid, kreg);
-        RT::load(vbase, rs, k0 + 128, S, hd, tid, vreg);
+  const int64_t v_off = (int64_t)H * hd;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  auto issue = [&](const int tile, const int buf_off, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    char* kb = smem + buf_off;
+#pragma unroll
+    for (int it = 0; it < NDMA; it++) {
+      const bf16_t* ks;
+      if constexpr (FULL) {
+        ks = kbase + (int64_t)tile * 64 * rs + dma_off[it];
+      } else {
+        int r = tile * 64 + dma_row[it];
+        r = r < S ? r : S - 1;
+        ks = kbase + (int64_t)r * rs + (dma_off[it] - dma_row[it] * (int)rs);
+      }
+      char* dst = kb + (it * NT + wu * 64) * 16;   // wave-uniform; the hardware adds lane * 16
+      if (dma_on) {
+        dma16(ks, lds_addr(dst));
+        dma16(ks + v_off, lds_addr(dst + RT::BYTES));
       }
     }
+  };
+  constexpr int BUFB = 2 * RT::BYTES, RINGB = NBUF * BUFB;
+  // compiler-visible vmcnt(0): the Q fragment loads are complete, so the compiler has no reason to drain vmcnt (and
+  // with it the DMA it cannot see) inside the loop
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll
+  for (int d = 0; d < DIST; d++)
+    if (d < nt) issue(d, d * BUFB, std::false_type{});
+  int cur_off = 0, nxt_off = DIST * BUFB;   // ring offsets of tile t and of tile t + DIST
+
+  // Steady-state iterations (FAST): tile t and the prefetched tile t+2 are both complete 64-key tiles with the full
+  // head dimension, so the loads carry no predicates and the key mask is not even computed; the last (up to three)
+  // iterations take the general path.  The soft-max arithmetic is written on 2-vectors so that the scale/subtract
+  // and the row sums issue as v_pk_fma_f32 / v_pk_add_f32 (the kernel is bound by VALU issue, not by MFMA).
+  const f32x2_t sc2 = {sc, sc};
+  auto iter = [&](const int t, auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int k0 = t * 64;
+    char* k_lds = smem + cur_off;
+    char* v_lds = k_lds + RT::BYTES;
+    // wait for this wave's DMA of tile t (tiles t+1 .. t+DIST-1 may stay in flight), then the barrier makes every
+    // wave's part of tile t visible and guarantees every wave is done with tile t-1, whose buffer tile t+DIST reuses
+    if (DIST >= 2 && (FAST || t + 1 < nt)) wait_vmcnt<2 * NDMA>();
+    else wait_vmcnt<0>();
+    raw_barrier();
+    if constexpr (FAST) issue(t + DIST, nxt_off, std::true_type{});
+    else if (t + DIST < nt) issue(t + DIST, nxt_off, std::false_type{});
+    cur_off = cur_off + BUFB == RINGB ? 0 : cur_off + BUFB;
+    nxt_off = nxt_off + BUFB == RINGB ? 0 : nxt_off + BUFB;
     // ---- S^T = K Q^T : sacc[qt][kt] holds S^T[key = kt*16 + 4g + r][q = li] ----
     f32x4_t sacc[QT][4];
 #pragma unroll
@@ -206,15 +279,16 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
       }
     // ---- online softmax (query = li, reduced over r, kt in-lane and over g across lanes 16/32 apart) ----
     bf16x8_t pf[QT][2];
-    const bool tail = (k0 + 64 > S);  // wave-uniform: only the last tile can hold padded keys
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
-      if (tail) {
+      if constexpr (!FAST) {
+        if (k0 + 64 > S) {  // wave-uniform: only the last tile can hold padded keys
 #pragma unroll
-        for (int kt = 0; kt < 4; kt++)
+          for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-          for (int r = 0; r < 4; r++)
-            if (k0 + kt * 16 + 4 * g + r >= S) sacc[qt][kt][r] = -INFINITY;
+            for (int r = 0; r < 4; r++)
+              if (k0 + kt * 16 + 4 * g + r >= S) sacc[qt][kt][r] = -INFINITY;
+        }
       }
       float mx = -INFINITY;
 #pragma unroll
@@ -236,23 +310,27 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
 #pragma unroll
         for (int dt = 0; dt < DT; dt++) oacc[qt][dt] *= alpha;
       }
-      float ls = 0.f;
+      const f32x2_t nm2 = {-mnew, -mnew};
+      f32x2_t ls2 = {0.f, 0.f};
+      f32x2_t pe[4][2];
 #pragma unroll
       for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][kt][r], sc, -mnew));
-          sacc[qt][kt][r] = p;
-          ls += p;
+        for (int hf = 0; hf < 2; hf++) {
+          const f32x2_t sv = {sacc[qt][kt][2 * hf], sacc[qt][kt][2 * hf + 1]};
+          const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nm2);
+          const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          pe[kt][hf] = e;
+          ls2 += e;
         }
-      lrun[qt] += ls;
+      lrun[qt] += ls2[0] + ls2[1];
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         u32x4_t pw;
-        pw[0] = cvt_pk_bf16(sacc[qt][2 * c][0], sacc[qt][2 * c][1]);
-        pw[1] = cvt_pk_bf16(sacc[qt][2 * c][2], sacc[qt][2 * c][3]);
-        pw[2] = cvt_pk_bf16(sacc[qt][2 * c + 1][0], sacc[qt][2 * c + 1][1]);
-        pw[3] = cvt_pk_bf16(sacc[qt][2 * c + 1][2], sacc[qt][2 * c + 1][3]);
+        pw[0] = cvt_pk_bf16(pe[2 * c][0][0], pe[2 * c][0][1]);
+        pw[1] = cvt_pk_bf16(pe[2 * c][1][0], pe[2 * c][1][1]);
+        pw[2] = cvt_pk_bf16(pe[2 * c + 1][0][0], pe[2 * c + 1][0][1]);
+        pw[3] = cvt_pk_bf16(pe[2 * c + 1][1][0], pe[2 * c + 1][1][1]);
         pf[qt][c] = __builtin_bit_cast(bf16x8_t, pw);
       }
     }
@@ -266,7 +344,12 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
         for (int qt = 0; qt < QT; qt++)
           oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
       }
-  }
+  };
+  const int nfull = (hd == HDP && RT::CAN_FULL) ? S / 64 : 0;   // complete tiles
+  const int t_fast = nfull - DIST > 0 ? nfull - DIST : 0;        // iterations t with tiles t and t+DIST complete
+  int t = 0;
+  for (; t < t_fast; t++) iter(t, std::true_type{});
+  for (; t < nt; t++) iter(t, std::false_type{});
 
 #pragma unroll
   for (int qt = 0; qt < QT; qt++) {
@@ -367,6 +450,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 
   u32x4_t qreg[RowTile<HDP>::NIT], doreg[RowTile<HDP>::NIT];
   float lse_r = 0.f, dl_r = 0.f;
+  const f32x2_t sc2 = {sc, sc};
   const int nt = (S + 63) / 64;
   auto load_tile = [&](int r0) {
     RowTile<HDP>::load(qbase, rs, r0, S, hd, tid, qreg);
@@ -403,12 +487,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
       }
       const float4 lse4 = *(const float4*)(lse_s + qt * 16 + 4 * g);   // queries qt*16 + 4g + {0..3}
       const float4 dl4 = *(const float4*)(dl_s + qt * 16 + 4 * g);
-      const float lse_a[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dl_a[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+      const f32x2_t nl[2] = {{-lse4.x, -lse4.y}, {-lse4.z, -lse4.w}}, dl2[2] = {{dl4.x, dl4.y}, {dl4.z, dl4.w}};
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -lse_a[r]));  // padded queries: lse = +inf -> 0
-        pv[qt][r] = p;
-        dsv[qt][r] = p * (dpacc[r] - dl_a[r]);
+      for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+        const f32x2_t sv = {sacc[2 * hf], sacc[2 * hf + 1]}, dpv = {dpacc[2 * hf], dpacc[2 * hf + 1]};
+        const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl[hf]);   // padded queries: lse = +inf -> P = 0
+        const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        const f32x2_t ds = e * (dpv - dl2[hf]);
+        pv[qt][2 * hf] = e[0];
+        pv[qt][2 * hf + 1] = e[1];
+        dsv[qt][2 * hf] = ds[0];
+        dsv[qt][2 * hf + 1] = ds[1];
       }
     }
 #pragma unroll
@@ -504,6 +593,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int dt = 0; dt < DT; dt++) dqacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   u32x4_t kreg[RowTile<HDP>::NIT], vreg[RowTile<HDP>::NIT];
+  const f32x2_t sc2 = {sc, sc};
   const int nt = (S + 63) / 64;
   RowTile<HDP>::load(kbase, rs, 0, S, hd, tid, kreg);
   RowTile<HDP>::load(vbase, rs, 0, S, hd, tid, vreg);
@@ -541,12 +631,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     bf16x8_t dsf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
+      const f32x2_t nl = {-lse_q[qt], -lse_q[qt]}, dl2 = {dl_q[qt], dl_q[qt]};
 #pragma unroll
       for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qt][kt][r], sc, -lse_q[qt]));
-          sacc[qt][kt][r] = p * (dpacc[qt][kt][r] - dl_q[qt]);
+        for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+          const f32x2_t sv = {sacc[qt][kt][2 * hf], sacc[qt][kt][2 * hf + 1]};
+          const f32x2_t dpv = {dpacc[qt][kt][2 * hf], dpacc[qt][kt][2 * hf + 1]};
+          const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl);
+          const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          const f32x2_t ds = e * (dpv - dl2);
+          sacc[qt][kt][2 * hf] = ds[0];
+          sacc[qt][kt][2 * hf + 1] = ds[1];
         }
 #pragma unroll
       for (int c = 0; c < 2; c++) {
