@@ -230,6 +230,19 @@ def main():
                          [m.shape[1] for m in me], [m.shape[1] for m in mp])
     step_tflops = fl / elapsed / 1e12  # per GPU
 
+    if os.environ.get("VJ_PHASE_TIMING"):   # diagnostics: where the main stream spends the step (after `value`)
+        trainer.phase_events = []
+        n_ph = 3
+        for i in range(n_ph):
+            run(args.warmup + i)
+        sync()
+        evs, trainer.phase_events = trainer.phase_events, None
+        acc = {}
+        for (n0, e0), (n1, e1) in zip(evs[:-1], evs[1:]):
+            key = n1 if n1 != "start" else "(between steps)"
+            acc[key] = acc.get(key, 0.0) + e0.elapsed_time(e1) / n_ph
+        log("main-stream phases, ms/step: " + json.dumps({k: round(v, 2) for k, v in acc.items()}))
+
     roof = None
     if not args.no_roofline_pass:
         from jepa_amd.engine.layers import side_stream

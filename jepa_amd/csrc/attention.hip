@@ -20,6 +20,7 @@
 // saves for the backward (an internal format, produced and consumed only here).
 #include "common.hpp"
 #include <type_traits>
+#include <cstdlib>
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
@@ -152,7 +153,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // =============================================================================================================
 // forward:  O = softmax(Q K^T * scale) V,  128 queries per workgroup (32 per wave), 64-key tiles
 // =============================================================================================================
-template <int HDP, int QT>
+template <int HDP, int QT, int NBUF>
 __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                        float* __restrict__ lse2, int B, int S, int H, int hd,
                                                        float sc, int nqb) {
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
   using RT = RowTile<HDP, NT>;
   // {K,V} x NBUF buffers, filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write): the DMA
   // destination is lane-linear, so the XOR swizzle of the row-major image is applied on the per-lane SOURCE chunk.
-  constexpr int NBUF = HDP <= 64 ? 3 : 2, DIST = NBUF - 1;   // prefetch distance in tiles
+  constexpr int DIST = NBUF - 1;   // prefetch distance in tiles
   static_assert(RT::CAN_FULL || NT == 512, "tile items must be a multiple of the workgroup size");
   constexpr int NDMA = RT::CAN_FULL ? RT::NIT : 1;            // DMA instructions per wave per K (or V) tile
   __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * RT::BYTES];
@@ -707,19 +708,24 @@ extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int
   const float sc = scale * LOG2E;
   // QT = 16-row query tiles per wave (QT = 1: 8 waves / workgroup, half the registers per wave).  Measured on
   // MI355X: QT = 2 is faster or equal for every head size (the kernel is bound by VALU issue, not by occupancy).
-#define VJ_FWD(HDPV, QTV)                                                                                            \
-  hipLaunchKernelGGL((attn_fwd_kernel<HDPV, QTV>), dim3((unsigned)nblk), dim3(8 * 64 / QTV), 0, stream,                \
+#define VJ_FWD(HDPV, QTV, NB)                                                                                        \
+  hipLaunchKernelGGL((attn_fwd_kernel<HDPV, QTV, NB>), dim3((unsigned)nblk), dim3(8 * 64 / QTV), 0, stream,            \
                      (const bf16_t*)qkv, (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb)
   const int qt_sel = g_attn_fwd_qt;
+  static const int nb_env = [] { const char* e = getenv("VJ_ATTN_NBUF"); return e ? atoi(e) : 0; }();
   switch (pick_hdp(hd)) {
     case 32:
-      if (qt_sel == 2) VJ_FWD(32, 2); else VJ_FWD(32, 1);
+      if (qt_sel != 2) VJ_FWD(32, 1, 3);
+      else if (nb_env == 2) VJ_FWD(32, 2, 2);
+      else VJ_FWD(32, 2, 3);
       break;
     case 64:
-      if (qt_sel == 2) VJ_FWD(64, 2); else VJ_FWD(64, 1);
+      if (qt_sel != 2) VJ_FWD(64, 1, 3);
+      else if (nb_env == 2) VJ_FWD(64, 2, 2);
+      else VJ_FWD(64, 2, 3);
       break;
     default:
-      if (qt_sel == 2) VJ_FWD(128, 2); else VJ_FWD(128, 1);
+      if (qt_sel == 2) VJ_FWD(128, 2, 2); else VJ_FWD(128, 1, 2);
   }
 #undef VJ_FWD
   VJ_LAUNCH_CHECK("vj_attn_fwd");

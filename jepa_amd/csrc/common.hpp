@@ -69,6 +69,42 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return 0.5f * (1.0f + e) + x * 0.3989422804014327f * g;
 }
 
+// ---- 2-wide versions for the GEMM epilogues: the polynomial, the products and the final combination issue as
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two elements per instruction); only rcp / exp2 / the sign handling stay
+// scalar.  q = 0.5 * erfc(|x|/sqrt2) = 0.5 * poly(t) * t * exp(-x^2/2) (same A-S 7.1.26 coefficients, halved).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void half_erfc2(f32x2_t x, f32x2_t& q, f32x2_t& gauss) {
+  const float k = 0.3275911f * 0.70710678118654752f;
+  f32x2_t t = {__builtin_amdgcn_rcpf(fmaf(k, fabsf(x[0]), 1.0f)), __builtin_amdgcn_rcpf(fmaf(k, fabsf(x[1]), 1.0f))};
+  const f32x2_t c = {-0.72134752044448170f, -0.72134752044448170f};   // -0.5 * log2(e)
+  const f32x2_t a = (x * c) * x;
+  gauss = (f32x2_t){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};   // exp(-x^2/2)
+  const f32x2_t c5 = {0.5f * 1.061405429f, 0.5f * 1.061405429f}, c4 = {0.5f * -1.453152027f, 0.5f * -1.453152027f},
+                 c3 = {0.5f * 1.421413741f, 0.5f * 1.421413741f}, c2 = {0.5f * -0.284496736f, 0.5f * -0.284496736f},
+                 c1 = {0.5f * 0.254829592f, 0.5f * 0.254829592f};
+  f32x2_t p = __builtin_elementwise_fma(c5, t, c4);
+  p = __builtin_elementwise_fma(p, t, c3);
+  p = __builtin_elementwise_fma(p, t, c2);
+  p = __builtin_elementwise_fma(p, t, c1);
+  q = (p * t) * gauss;
+}
+// gelu(x) = x * Phi(x) = max(x, 0) - |x * q|
+__device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
+  f32x2_t q, g;
+  half_erfc2(x, q, g);
+  const f32x2_t h = x * q;
+  return (f32x2_t){fmaxf(x[0], 0.f) - fabsf(h[0]), fmaxf(x[1], 0.f) - fabsf(h[1])};
+}
+// gelu'(x) = Phi(x) + x * pdf(x),  Phi(x) = 0.5 + copysign(0.5 - q, x)
+__device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {
+  f32x2_t q, g;
+  half_erfc2(x, q, g);
+  const f32x2_t half = {0.5f, 0.5f}, a = half - q;
+  const f32x2_t phi = half + (f32x2_t){copysignf(a[0], x[0]), copysignf(a[1], x[1])};
+  const f32x2_t c = {0.3989422804014327f, 0.3989422804014327f};
+  return __builtin_elementwise_fma(x * c, g, phi);
+}
+
 // ---- host side error plumbing (no C++ exception crosses the C ABI) ----
 extern "C" const char* vj_last_error(void);
 void vj_set_error(const char* fmt, ...);

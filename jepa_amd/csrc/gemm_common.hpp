@@ -23,83 +23,143 @@ struct GemmArgs {
 
 // Fused epilogue.  acc[i][j] comes from MFMA 16x16x32 issued with swapped operands (D = Bfrag x Afrag): lane
 // (g = lane>>4, r = lane&15) owns row m = .. + i*16 + r and the 4 consecutive columns n = .. + j*16 + 4g + {0..3}.
+//
+// The body is deliberately STRAIGHT-LINE code: on gfx9 stores count in vmcnt together with loads, and the compiler's
+// wait-count insertion falls back to `s_waitcnt vmcnt(0)` -- i.e. "drain every store issued so far" -- at each use of a
+// loaded value once control flow separates the load from the use.  So there are no `continue`s and no per-block
+// branches here: edge rows / columns are handled by clamping load addresses and predicating the stores only, the
+// nullable operands are resolved once by the caller-side variant switch (HAS_OPT), the bias is complete before the
+// first row (one explicit wait), and the row operands (residual / saved pre-activation) are fetched one row-block ahead
+// so that a row's stores stay in flight while the next row is computed.
+template <int EPI, int FM, int FN, bool HAS_OPT, bool EDGE, bool BETA = false>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int64_t m_base,
+                                                   int64_t n_base, int frow, int fg, int slice) {
+  const int64_t ncol0 = n_base + fg * 4;   // this lane's first column; tile j adds j*16
+  bool cok[FN];
+  int64_t ncl[FN];                         // column for loads, clamped into the matrix (N % 4 == 0, N >= 4)
+#pragma unroll
+  for (int j = 0; j < FN; j++) {
+    const int64_t n = ncol0 + j * 16;
+    cok[j] = EDGE ? n < p.N : true;
+    ncl[j] = cok[j] ? n : 0;
+  }
+  float4 bias4[FN];
+#pragma unroll
+  for (int j = 0; j < FN; j++) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (EPI != EPI_F32) {
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < FN; j++) bias4[j] = *(const float4*)(p.bias + ncl[j]);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), visible to the compiler: nothing older than the epilogue is pending
+
+  if constexpr (EPI == EPI_F32) {
+    // HAS_OPT = split-K: raw partials into ws[slice]; alpha / beta are applied by the slice reduction
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      const int64_t m = m_base + i * 16 + frow;
+      const bool mok = EDGE ? m < p.M : true;
+      const int64_t mc = mok ? m : p.M - 1;
+      float* c32 = (float*)p.C + mc * p.ldc;
+      float* wsp = p.ws + ((int64_t)slice * p.M + mc) * p.N;
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if constexpr (HAS_OPT) {
+          if (mok && cok[j]) *(float4*)(wsp + ncl[j]) = o;
+        } else {
+          o.x *= p.alpha;
+          o.y *= p.alpha;
+          o.z *= p.alpha;
+          o.w *= p.alpha;
+          if constexpr (BETA) {   // accumulate into C (not used on the training path: every wgrad overwrites)
+            const float4 c0 = *(const float4*)(c32 + ncl[j]);
+            o.x += p.beta * c0.x;
+            o.y += p.beta * c0.y;
+            o.z += p.beta * c0.z;
+            o.w += p.beta * c0.w;
+          }
+          if (mok && cok[j]) *(float4*)(c32 + ncl[j]) = o;
+        }
+      }
+    }
+  } else {
+    // row operand: residual (EPI_BF16 with HAS_OPT) or saved pre-activation (EPI_DGELU); HAS_OPT for EPI_GELU = write u
+    constexpr bool HAS_OPND = (EPI == EPI_DGELU) || (EPI == EPI_BF16 && HAS_OPT);
+    const bf16_t* opnd_p = (EPI == EPI_DGELU) ? p.aux_in : p.res;
+    const int64_t opnd_ld = (EPI == EPI_DGELU) ? p.ldaux : p.ldr;
+    u32x2_t opnd[2][FN];
+    auto load_row = [&](int i, u32x2_t* dst) {
+      int64_t m = m_base + i * 16 + frow;
+      if constexpr (EDGE) m = m < p.M ? m : p.M - 1;
+      const bf16_t* base = opnd_p + m * opnd_ld;
+#pragma unroll
+      for (int j = 0; j < FN; j++) dst[j] = *(const u32x2_t*)(base + ncl[j]);
+    };
+    if constexpr (HAS_OPND) load_row(0, opnd[0]);
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      if constexpr (HAS_OPND) {
+        if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
+      }
+      const int64_t m = m_base + i * 16 + frow;
+      const bool mok = EDGE ? m < p.M : true;
+      const int64_t mc = mok ? m : p.M - 1;
+      bf16_t* c16 = (bf16_t*)p.C + mc * p.ldc;
+      bf16_t* auxo = (EPI == EPI_GELU && HAS_OPT) ? p.aux_out + mc * p.ldaux : nullptr;
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        f32x2_t v01 = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y};
+        f32x2_t v23 = {acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+        if constexpr (EPI == EPI_GELU) {
+          u32x2_t u;
+          u[0] = pack_bf2(v01[0], v01[1]);
+          u[1] = pack_bf2(v23[0], v23[1]);
+          if constexpr (HAS_OPT) {
+            if (mok && cok[j]) *(u32x2_t*)(auxo + ncl[j]) = u;
+          }
+          // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
+          v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+          v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
+        } else if constexpr (EPI == EPI_DGELU) {
+          const u32x2_t u = opnd[i & 1][j];
+          v01 *= dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+          v23 *= dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
+        } else if constexpr (HAS_OPT) {
+          const u32x2_t r2 = opnd[i & 1][j];
+          v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
+          v23 += (f32x2_t){bf_lo(r2[1]), bf_hi(r2[1])};
+        }
+        u32x2_t o;
+        o[0] = pack_bf2(v01[0], v01[1]);
+        o[1] = pack_bf2(v23[0], v23[1]);
+        if (mok && cok[j]) *(u32x2_t*)(c16 + ncl[j]) = o;
+      }
+    }
+  }
+}
+
 template <int EPI, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int64_t m_base,
                                               int64_t n_base, int frow, int fg, int slice) {
-  const int64_t ncol0 = n_base + fg * 4;   // this lane's first column; tile j adds j*16
-  float4 bias4[FN];
-  if constexpr (EPI != EPI_F32) {
-#pragma unroll
-    for (int j = 0; j < FN; j++) {
-      const int64_t n = ncol0 + j * 16;
-      bias4[j] = (p.bias && n < p.N) ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < FM; i++) {
-    const int64_t m = m_base + i * 16 + frow;
-    if (m >= p.M) continue;
-    // row base pointers, computed once per row
-    float* c32 = (float*)p.C + m * p.ldc + ncol0;
-    bf16_t* c16 = (bf16_t*)p.C + m * p.ldc + ncol0;
-    float* wsp = p.ws + ((int64_t)slice * p.M + m) * p.N + ncol0;
-    const bf16_t* resp = p.res ? p.res + m * p.ldr + ncol0 : nullptr;
-    const bf16_t* auxi = p.aux_in ? p.aux_in + m * p.ldaux + ncol0 : nullptr;
-    bf16_t* auxo = p.aux_out ? p.aux_out + m * p.ldaux + ncol0 : nullptr;
-#pragma unroll
-    for (int j = 0; j < FN; j++) {
-      if (ncol0 + j * 16 >= p.N) continue;  // N % 4 == 0 is enforced by the host wrapper
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if constexpr (EPI == EPI_F32) {
-        if (p.splitk > 1) {  // raw partial; alpha/beta are applied by the slice reduction
-          *(float4*)(wsp + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
-          continue;
-        }
-        float4 o = make_float4(v[0] * p.alpha, v[1] * p.alpha, v[2] * p.alpha, v[3] * p.alpha);
-        if (p.beta != 0.f) {
-          const float4 c0 = *(const float4*)(c32 + j * 16);
-          o.x += p.beta * c0.x;
-          o.y += p.beta * c0.y;
-          o.z += p.beta * c0.z;
-          o.w += p.beta * c0.w;
-        }
-        *(float4*)(c32 + j * 16) = o;
-      } else {
-        v[0] += bias4[j].x;
-        v[1] += bias4[j].y;
-        v[2] += bias4[j].z;
-        v[3] += bias4[j].w;
-        if constexpr (EPI == EPI_GELU) {
-          u32x2_t u;
-          u[0] = pack_bf2(v[0], v[1]);
-          u[1] = pack_bf2(v[2], v[3]);
-          if (auxo) *(u32x2_t*)(auxo + j * 16) = u;
-          // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
-          v[0] = gelu_f(bf_lo(u[0]));
-          v[1] = gelu_f(bf_hi(u[0]));
-          v[2] = gelu_f(bf_lo(u[1]));
-          v[3] = gelu_f(bf_hi(u[1]));
-        } else if constexpr (EPI == EPI_DGELU) {
-          const u32x2_t u = *(const u32x2_t*)(auxi + j * 16);
-          v[0] *= dgelu_f(bf_lo(u[0]));
-          v[1] *= dgelu_f(bf_hi(u[0]));
-          v[2] *= dgelu_f(bf_lo(u[1]));
-          v[3] *= dgelu_f(bf_hi(u[1]));
-        } else {
-          if (resp) {
-            const u32x2_t r2 = *(const u32x2_t*)(resp + j * 16);
-            v[0] += bf_lo(r2[0]);
-            v[1] += bf_hi(r2[0]);
-            v[2] += bf_lo(r2[1]);
-            v[3] += bf_hi(r2[1]);
-          }
-        }
-        u32x2_t o;
-        o[0] = pack_bf2(v[0], v[1]);
-        o[1] = pack_bf2(v[2], v[3]);
-        *(u32x2_t*)(c16 + j * 16) = o;
-      }
-    }
+  bool opt;   // workgroup-uniform: resolved once, each variant is branch-free inside
+  if constexpr (EPI == EPI_F32) opt = p.splitk > 1;
+  else if constexpr (EPI == EPI_GELU) opt = p.aux_out != nullptr;
+  else if constexpr (EPI == EPI_BF16) opt = p.res != nullptr;
+  else opt = true;
+  // interior wave tiles (the vast majority) carry no predicates at all
+  const bool edge = __builtin_amdgcn_readfirstlane((m_base + FM * 16 > p.M) || (n_base + FN * 16 > p.N));
+  if (opt) {
+    if (edge) gemm_epilogue_impl<EPI, FM, FN, true, true>(p, acc, m_base, n_base, frow, fg, slice);
+    else gemm_epilogue_impl<EPI, FM, FN, true, false>(p, acc, m_base, n_base, frow, fg, slice);
+  } else if constexpr (EPI == EPI_F32) {
+    if (p.beta != 0.f) gemm_epilogue_impl<EPI, FM, FN, false, true, true>(p, acc, m_base, n_base, frow, fg, slice);
+    else if (edge) gemm_epilogue_impl<EPI, FM, FN, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+    else gemm_epilogue_impl<EPI, FM, FN, false, false>(p, acc, m_base, n_base, frow, fg, slice);
+  } else if constexpr (EPI != EPI_DGELU) {
+    if (edge) gemm_epilogue_impl<EPI, FM, FN, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+    else gemm_epilogue_impl<EPI, FM, FN, false, false>(p, acc, m_base, n_base, frow, fg, slice);
   }
 }
 

@@ -160,6 +160,8 @@ class Trainer:
         B = clips.shape[0]
         D = self.vit.embed_dim
         n_masks = len(masks_pred)
+        mark = self._phase_mark
+        mark('start')
         # ---- forward: the EMA target branch is independent of the context branch until the loss, so it runs on
         #      the side stream concurrently (fills the tails of each other's kernels)
         side = side_stream(self.device)
@@ -171,6 +173,7 @@ class Trainer:
             h = self.forward_target(clips, masks_pred)
         z, segs, saved_e = encoder_forward(self.ew, clips, masks_enc, save=True)
         zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, masks_enc, masks_pred, save=True)
+        mark('context+predictor forward (main stream)')
         if side.enabled:
             side.join()
             for t in h:
@@ -195,16 +198,29 @@ class Trainer:
             for i, t in enumerate(tsegs):
                 ops.reg_grad(zhat[t.row0:t.row0 + t.rows], pstd, stats[i], dzhat[t.row0:t.row0 + t.rows], B, t.S, D,
                              n_masks, coef)
+        mark('target forward joined + loss')
         # ---- backward (predictor first, then encoder layers 23..0); gradient buckets go out as layers finish
         side = side_stream(self.device)
         self.reducer.begin(side.stream if side.enabled else None)
         hook = self.reducer.layer_done if self.reducer.enabled else None
         dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=hook)
+        mark('predictor backward (main stream)')
         encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=hook)
+        mark('encoder backward (main stream)')
         self.reducer.finish()
         # ---- clip / AdamW / EMA / bf16 re-cast (train.py:461-487)
         norms = self.optimizer_step(lr, wd, ema, clip_now)
+        mark('wgrad stream joined + AdamW/EMA')
         return StepOutput(self._stat[:2].clone(), self.reg_coeff, lr, wd, ema, norms)
+
+    def _phase_mark(self, name):
+        """Phase timestamps on the main stream (tools / bench diagnostics): set `self.phase_events = []` to collect
+        (name, event) pairs for the following steps; None (default) costs nothing."""
+        ev = getattr(self, 'phase_events', None)
+        if ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append((name, e))
 
     # ------------------------------------------------------------------------------------------------ update
     def _grad_sqnorms(self):
