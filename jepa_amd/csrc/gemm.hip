@@ -14,10 +14,13 @@
 // CONSECUTIVE output columns: 8-byte bf16 / 16-byte fp32 epilogue accesses for C, bias, residual and aux.
 // Workgroup ids are remapped so every XCD (private L2) works on a contiguous band of tiles.
 #include "gemm_common.hpp"
+#include <cstdlib>
 
 // tile configurations: <BM, BN, WM, WN> = block tile and wave grid; each wave owns (BM/WM) x (BN/WN)
 //   128x128, 2x2 waves (64x64 per wave)  : 64 KB LDS, 2 workgroups / CU -- small / skinny problems
 //   256x256, 2x4 waves (128x64 per wave) : 128 KB LDS, 1 workgroup / CU, 2 waves / SIMD -- 2x the L2->LDS reuse
+//   256x128, 2x2 waves (128x64 per wave) : BK32 x 3 stages = 72 KB, 2 INDEPENDENT workgroups / CU: one workgroup's
+//                                          prologue / epilogue overlaps the other's K loop (short-K shapes)
 
 // 16-byte-chunk XOR swizzle of a tile row (rows are BK*2 bytes): makes every ds_read_b128 lane group of a fragment
 // read hit 16 distinct 16-byte slots of the 256-byte bank row.  BK=64 (8 chunks/row): chunk ^= row&7.
@@ -64,12 +67,7 @@ __device__ __forceinline__ void stage_commit(char* lds_tile, int tid, const u32x
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 0 ? N : 0) : "memory");
 }
 
 // NS = LDS ring depth.  NS == 2 is the classic double buffer (stage t+1 while multiplying t, drain before the
@@ -77,7 +75,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // s_waitcnt vmcnt (never 0 in steady state) and a raw s_barrier, which is what hides HBM/L2 latency when the
 // K loop is short (K = 1024 / 384 in this model).
 template <int BK, int NS, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(GLDS || NS == 2, "register staging supports only the double buffer");
   constexpr int NT = WM * WN * 64;
@@ -282,6 +280,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
   if (cfg == 0) cfg = 1;
   if (pipe == 0) pipe = 1;       // BK64 double buffer (beats the BK32 ring on every step shape)
   if (a.K % 64 != 0) pipe = 2;   // K % 32 only fits the BK32 pipeline
+  if (cfg == 3) pipe = 2;
   if (pipe == 3 && a.K % 64 == 0 && !reg_staged) return vj_gemm_launch_8phase(a, EPI, ws, ws_bytes, stream);
   if (pipe == 3) pipe = 1;
   if (reg_staged) {
@@ -292,6 +291,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
   if (pipe == 1)
     return cfg == 2 ? launch_gemm<64, 2, EPI, true, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
                     : launch_gemm<64, 2, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
+  if (cfg == 3) return launch_gemm<32, 3, EPI, true, 256, 128, 2, 2>(a, ws, ws_bytes, stream);
   return cfg == 2 ? launch_gemm<32, 4, EPI, true, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
                   : launch_gemm<32, 4, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
 }
@@ -319,6 +319,10 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.alpha = alpha; a.beta = beta;
   a.tiles_m = a.tiles_n = 0; a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
+  static const int dbg_env = [] { const char* e = getenv("VJ_GEMM_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg_env;
+  static const int skew_env = [] { const char* e = getenv("VJ_GEMM_SKEW"); return e ? atoi(e) : 0; }();
+  a.skew_step = skew_env;
   switch (epilogue) {
     case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, nullptr, 0, stream);
     case EPI_GELU: return dispatch_gemm<EPI_GELU>(a, flags, nullptr, 0, stream);

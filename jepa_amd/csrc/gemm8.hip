@@ -91,6 +91,15 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
   const int nk = (kt0 + p.ktiles_per < nk_all ? kt0 + p.ktiles_per : nk_all) - kt0;
   const int last_part = 4 * nk - 2;   // parts: -1 (A0 of tile 0), then per tile B0, B1, A1 and A0 of the next tile
 
+  // Start-up skew.  All workgroups of a round finish their K loop together, and the 256 simultaneous 128 KB epilogue
+  // bursts (33 MB) then drain at the fabric's write rate for 7-9 us while every MFMA idles (tools/gemm_ksweep.py:
+  // 12 us fixed cost per tile round with the stores, 3-5 us without).  Delaying the first-round workgroups by up to
+  // ~skew_us spreads the epilogues of every following round in time.  dbg bits 8.. = skew step in units of 64 clocks.
+  if (p.skew_step > 0 && blockIdx.x < 256) {
+    const int steps = (blockIdx.x >> 3) & 7;   // XCD = blockIdx % 8: the CUs of one XCD get 8 different delays
+    for (int i = 0; i < steps * p.skew_step; i++) __builtin_amdgcn_s_sleep(1);
+  }
+
   f32x4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; i++)
@@ -216,7 +225,18 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
     }
   }
   if (!late_group) bar();   // the early group matches the late group's extra barrier
-  gemm_epilogue<EPI, 8, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, frow, fg, slice);
+  if (p.dbg & 1) {   // diagnostics: no output traffic (keeps the accumulators alive through one predicated store)
+    if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 0.5f) *(float*)p.C = acc[3][2][1];
+    return;
+  }
+  // every wave is past its last LDS read and every DMA has landed: the ring is free, 16 KB of it per wave.
+  // The lane id is re-derived here (mbcnt) so that nothing epilogue-only stays live across the K loop (256 VGPRs).
+  const int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int efrow = elane & 15, efg = elane >> 4;
+  if (!(p.dbg & 2) && gemm_epilogue_try_staged<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+                                                    smem + wave_u * 16384))
+    return;
+  gemm_epilogue<EPI, 8, 4, /*INTERIOR_VARIANT=*/(EPI == EPI_F32)>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, slice);
 }
 
 __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, int64_t N, int64_t ldc, int S,

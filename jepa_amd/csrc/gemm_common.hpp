@@ -18,6 +18,8 @@ struct GemmArgs {
   int splitk;          // > 1: K is cut into `splitk` slices, raw fp32 partials go to ws[slice][M][N] (EPI_F32 only)
   int ktiles_per;      // K-tiles per slice
   float* ws;
+  int skew_step;       // first-round start-up skew: step in units of 64 clocks per delay slot (0 = off), gemm8.hip
+  int dbg;             // diagnostics (VJ_GEMM_DBG): bit0 = skip the epilogue stores, bit1 = 16-byte stores
 };
 
 
@@ -140,7 +142,147 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
   }
 }
 
-template <int EPI, int FM, int FN>
+// bf16 epilogues of the 128 x 64 wave tile (8 x 4 MFMA blocks) staged through LDS.  In the MFMA C layout a store
+// instruction covers 16 rows x 32 bytes: sixteen partial-line writes, and the L1 write path spends ~4 clocks on each
+// (tools/gemm_ksweep.py: 7-9 us per 256 x 256 tile, ~25 % of a K = 1024 tile).  Here every wave converts its tile to
+// bf16, parks it in a private 16 KB LDS region (the operand ring is dead by now; 8-byte writes, 16-byte chunks XOR-
+// swizzled by (row >> 1) & 7: conflict-free reads, 2-way writes that hide under the ds_write data transfer) and reads
+// it back row-major: one ds_read_b128 + one 16-byte store per lane, eight complete 128-byte lines per instruction.
+// The arithmetic (bias, residual, GELU) stays in the MFMA layout and is identical to gemm_epilogue_impl.
+template <int EPI, bool HAS_OPT, bool EDGE>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
+                                                     int64_t n_base, int frow, int fg, int lane, char* stage) {
+  static_assert(EPI != EPI_F32, "fp32 outputs are stored directly");
+  constexpr int FM = 8, FN = 4;
+  const int64_t ncol0 = n_base + fg * 4;
+  int64_t ncl[FN];
+#pragma unroll
+  for (int j = 0; j < FN; j++) {
+    const int64_t n = ncol0 + j * 16;
+    ncl[j] = (!EDGE || n < p.N) ? n : 0;
+  }
+  float4 bias4[FN];
+#pragma unroll
+  for (int j = 0; j < FN; j++) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < FN; j++) bias4[j] = *(const float4*)(p.bias + ncl[j]);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
+
+  // LDS addresses: write (MFMA layout) and read-back (row-major) sides of the same swizzled image
+  int wr_off[FN];
+  {
+    const int key = (frow >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < FN; j++) wr_off[j] = frow * 128 + (((j * 2 + (fg >> 1)) ^ key) << 4) + (fg & 1) * 8;
+  }
+  const int rrow = lane >> 3, rch = lane & 7;   // read-back: 8 lanes per 128-byte row, 8 rows per instruction
+  int rd_off[2];
+#pragma unroll
+  for (int par = 0; par < 2; par++) rd_off[par] = rrow * 128 + ((rch ^ ((par * 4 + (rrow >> 1)) & 7)) << 4);
+  const bool col_ok = !EDGE || (n_base + rch * 8 < p.N);
+
+  auto flush = [&](bf16_t* out, int64_t ld) {   // LDS image -> global, 16 x (ds_read_b128 + 16-byte store)
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const u32x4_t v = *(const u32x4_t*)(stage + it * 1024 + rd_off[it & 1]);
+      const int64_t m = m_base + it * 8 + rrow;
+      if (col_ok && (!EDGE || m < p.M)) *(u32x4_t*)(out + m * ld + n_base + rch * 8) = v;
+    }
+  };
+
+  constexpr bool HAS_OPND = (EPI == EPI_DGELU) || (EPI == EPI_BF16 && HAS_OPT);
+  constexpr bool TWO_OUT = (EPI == EPI_GELU) && HAS_OPT;
+  const bf16_t* opnd_p = (EPI == EPI_DGELU) ? p.aux_in : p.res;
+  const int64_t opnd_ld = (EPI == EPI_DGELU) ? p.ldaux : p.ldr;
+  u32x2_t opnd[2][FN];
+  auto load_row = [&](int i, u32x2_t* dst) {
+    int64_t m = m_base + i * 16 + frow;
+    if constexpr (EDGE) m = m < p.M ? m : p.M - 1;
+    const bf16_t* base = opnd_p + m * opnd_ld;
+#pragma unroll
+    for (int j = 0; j < FN; j++) dst[j] = *(const u32x2_t*)(base + ncl[j]);
+  };
+  if constexpr (HAS_OPND) load_row(0, opnd[0]);
+  u32x2_t second[TWO_OUT ? FM : 1][FN];   // GELU outputs wait here (packed bf16) while the pre-activations go out
+#pragma unroll
+  for (int i = 0; i < FM; i++) {
+    if constexpr (HAS_OPND) {
+      if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      f32x2_t v01 = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y};
+      f32x2_t v23 = {acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+      u32x2_t o;
+      if constexpr (EPI == EPI_GELU) {
+        u32x2_t u;
+        u[0] = pack_bf2(v01[0], v01[1]);
+        u[1] = pack_bf2(v23[0], v23[1]);
+        // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
+        v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+        v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
+        o[0] = pack_bf2(v01[0], v01[1]);
+        o[1] = pack_bf2(v23[0], v23[1]);
+        if constexpr (TWO_OUT) {
+          second[i][j] = o;
+          o = u;
+        }
+      } else {
+        if constexpr (EPI == EPI_DGELU) {
+          const u32x2_t u = opnd[i & 1][j];
+          v01 *= dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+          v23 *= dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
+        } else if constexpr (HAS_OPT) {
+          const u32x2_t r2 = opnd[i & 1][j];
+          v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
+          v23 += (f32x2_t){bf_lo(r2[1]), bf_hi(r2[1])};
+        }
+        o[0] = pack_bf2(v01[0], v01[1]);
+        o[1] = pack_bf2(v23[0], v23[1]);
+      }
+      *(u32x2_t*)(stage + i * 2048 + wr_off[j]) = o;
+    }
+  }
+  if constexpr (TWO_OUT) {
+    flush(p.aux_out, p.ldaux);
+#pragma unroll
+    for (int i = 0; i < FM; i++)
+#pragma unroll
+      for (int j = 0; j < FN; j++) *(u32x2_t*)(stage + i * 2048 + wr_off[j]) = second[i][j];
+  }
+  flush((bf16_t*)p.C, p.ldc);
+}
+
+// staged variant selector for the 8-phase kernel (wave tile 128 x 64); falls back to the direct form when the 16-byte
+// row-major stores cannot be used (N, ldc or the base pointers not 8-element aligned) and for fp32 outputs
+template <int EPI>
+__device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
+                                                         int64_t n_base, int frow, int fg, int lane, char* stage) {
+  if constexpr (EPI == EPI_F32) {
+    return false;
+  } else {
+    bool ok = (p.N % 8 == 0) && (p.ldc % 8 == 0) && (((uintptr_t)p.C & 15) == 0);
+    if constexpr (EPI == EPI_GELU) ok = ok && (p.aux_out == nullptr || ((p.ldaux % 8 == 0) && (((uintptr_t)p.aux_out & 15) == 0)));
+    if (!ok) return false;
+    bool opt;
+    if constexpr (EPI == EPI_GELU) opt = p.aux_out != nullptr;
+    else if constexpr (EPI == EPI_BF16) opt = p.res != nullptr;
+    else opt = true;
+    const bool edge = __builtin_amdgcn_readfirstlane((m_base + 128 > p.M) || (n_base + 64 > p.N));
+    if (opt) {
+      if (edge) gemm_epilogue_staged<EPI, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      else gemm_epilogue_staged<EPI, true, false>(p, acc, m_base, n_base, frow, fg, lane, stage);
+    } else if constexpr (EPI != EPI_DGELU) {
+      if (edge) gemm_epilogue_staged<EPI, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      else gemm_epilogue_staged<EPI, false, false>(p, acc, m_base, n_base, frow, fg, lane, stage);
+    }
+    return true;
+  }
+}
+
+template <int EPI, int FM, int FN, bool INTERIOR_VARIANT = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int64_t m_base,
                                               int64_t n_base, int frow, int fg, int slice) {
   bool opt;   // workgroup-uniform: resolved once, each variant is branch-free inside
@@ -149,7 +291,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
   else if constexpr (EPI == EPI_BF16) opt = p.res != nullptr;
   else opt = true;
   // interior wave tiles (the vast majority) carry no predicates at all
-  const bool edge = __builtin_amdgcn_readfirstlane((m_base + FM * 16 > p.M) || (n_base + FN * 16 > p.N));
+  const bool edge =
+      !INTERIOR_VARIANT || __builtin_amdgcn_readfirstlane((m_base + FM * 16 > p.M) || (n_base + FN * 16 > p.N));
   if (opt) {
     if (edge) gemm_epilogue_impl<EPI, FM, FN, true, true>(p, acc, m_base, n_base, frow, fg, slice);
     else gemm_epilogue_impl<EPI, FM, FN, true, false>(p, acc, m_base, n_base, frow, fg, slice);
