@@ -233,11 +233,11 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
   if (EPI == EPI_F32 && ws != nullptr) {
     // wgrad: fill the chip (>= 2 waves of workgroups); each slice keeps >= 8 K-tiles of work
     const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
-    int64_t s = cdiv64(512, tiles);
-    const int64_t max_by_k = nk / 8 > 0 ? nk / 8 : 1;
-    if (s > max_by_k) s = max_by_k;
-    while (s > 1 && s * a.M * a.N * 4 > ws_bytes) s--;
-    b.splitk = (int)s;
+    // concurrent workgroups per round: 2 per CU for the 4-wave tiles, 1 per CU for 256x256; K-tile time scales with
+    // the tile area and BK
+    const int slots = (BM * BN >= 256 * 256) ? 256 : 512;
+    const double us_kt = 1.45 * ((double)BM * BN * BK) / (256.0 * 256.0 * 64.0) * (slots == 512 ? 2.6 : 1.3);
+    b.splitk = pick_splitk(tiles, nk, slots, us_kt, 8, a.M, a.N, ws_bytes);
     b.ws = (float*)ws;
   }
   b.ktiles_per = (nk + b.splitk - 1) / b.splitk;
@@ -273,9 +273,8 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     // forward / dgrad shape with >= ~90 tiles except the N=1152, K=384 predictor qkv; split-K wgrads (few tiles,
     // long K) stay on 128x128 with 2 workgroups per CU.
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
-    const bool narrow = (a.K < 512 && a.N > 1024 && a.N < 1536);
-    if (!is_wgrad && a.K % 64 == 0 && t256 >= 90 && !narrow) pipe = 3;
-    if (is_wgrad && a.K % 64 == 0 && t256 >= 64) pipe = 3;   // fc1/fc2 wgrads: 8-phase + split-K (1.05 vs 0.95 PF)
+    if (!is_wgrad && a.K % 64 == 0 && t256 >= 90) pipe = 3;
+    if (is_wgrad && a.K % 64 == 0 && t256 >= 40) pipe = 3;   // qkv/fc1/fc2 wgrads: 8-phase + split-K (0.97-1.08 vs 0.78-0.96 PF)
   }
   if (cfg == 0) cfg = 1;
   if (pipe == 0) pipe = 1;       // BK64 double buffer (beats the BK32 ring on every step shape)

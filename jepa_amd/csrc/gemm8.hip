@@ -258,11 +258,7 @@ static int launch8(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t st
   const int nk = (int)(a.K / P8_BK);
   if (EPI == EPI_F32 && ws != nullptr) {   // wgrad: one workgroup per CU needs >= ~256 of them; >= 8 K-tiles per slice
     const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
-    int64_t s = cdiv64(256, tiles);
-    const int64_t max_by_k = nk / 8 > 0 ? nk / 8 : 1;
-    if (s > max_by_k) s = max_by_k;
-    while (s > 1 && s * a.M * a.N * 4 > ws_bytes) s--;
-    b.splitk = (int)s;
+    b.splitk = pick_splitk(tiles, nk, 256, 1.45, 8, a.M, a.N, ws_bytes);
     b.ws = (float*)ws;
   }
   b.ktiles_per = (nk + b.splitk - 1) / b.splitk;

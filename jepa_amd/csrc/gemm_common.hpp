@@ -306,6 +306,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
   }
 }
 
+// Split-K factor for the fp32 weight-gradient GEMMs (few output tiles, very long K).  Cost model in units of one K-tile
+// of one workgroup round: rounds x (K-tiles per slice + fixed per-workgroup overhead) + the HBM time of writing and
+// re-reading the `s` fp32 partial matrices.  Picks whole rounds of `slots` concurrent workgroups instead of the
+// "just above one round" counts a plain ceil() produces (48 tiles x 6 slices = 288 workgroups = two rounds at 56 %).
+static inline int pick_splitk(int64_t tiles, int nk, int slots, double us_per_ktile, int min_ktiles, int64_t M,
+                              int64_t N, int64_t ws_bytes) {
+  int64_t smax = nk / min_ktiles > 0 ? nk / min_ktiles : 1;
+  if (smax > 64) smax = 64;
+  while (smax > 1 && smax * M * N * 4 > ws_bytes) smax--;
+  const double partial_us = 2.0 * (double)M * (double)N * 4.0 / 3.0e6;   // write + read of one partial at ~3 TB/s
+  int best = 1;
+  double best_cost = 1e30;
+  for (int64_t sk = 1; sk <= smax; sk++) {
+    const int64_t per = (nk + sk - 1) / sk;
+    const int64_t eff = (nk + per - 1) / per;   // no empty slices
+    if (eff != sk) continue;
+    const int64_t rounds = (tiles * sk + slots - 1) / slots;
+    const double cost = (double)rounds * ((double)per + 4.0) * us_per_ktile + (sk > 1 ? (double)sk * partial_us : 0.0);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = (int)sk;
+    }
+  }
+  return best;
+}
+
 // XCD-aware, grouped tile mapping (bijective for any grid size): workgroup `bid` of `nblk` -> logical tile index such
 // that each XCD (private L2; hardware dispatches workgroup b to XCD b % 8) works on a contiguous band of tiles.
 __device__ __forceinline__ int xcd_logical(int bid, int nblk) {
