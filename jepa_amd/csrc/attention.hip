@@ -139,6 +139,41 @@ struct TrFrag {
   }
 };
 
+// ---- LDS-DMA staging of one 64-row tile of TWO row-major operands (X at +0, Y at +RowTile::BYTES of a ring buffer) ----
+// Used by the backward kernels (the forward kernel carries its own copy of the same scheme).  Rows beyond `nrows`
+// re-read row nrows-1 and chunks beyond the real head dimension re-read chunk 0: the callers mask such rows / never
+// use such columns, so the DMA needs no zero fill.
+template <int HDP, int NT>
+struct TileDma {
+  using RT = RowTile<HDP, NT>;
+  static_assert(RT::CAN_FULL, "tile items must be a multiple of the workgroup size");
+  static constexpr int NDMA = RT::NIT;
+  int row[NDMA], col[NDMA];
+  int wu;
+  __device__ __forceinline__ TileDma(int tid, int hd) {
+    wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int it = 0; it < NDMA; it++) {
+      const int item = tid + it * NT;
+      const int r = item / RT::CHP, c = (item % RT::CHP) ^ rm_swz<HDP>(r);
+      row[it] = r;
+      col[it] = c * 8 < hd ? c * 8 : 0;
+    }
+  }
+  template <bool FULL>
+  __device__ __forceinline__ void issue(const bf16_t* xb, int64_t rsx, const bf16_t* yb, int64_t rsy, int r0, int nrows,
+                                        char* buf) const {
+#pragma unroll
+    for (int it = 0; it < NDMA; it++) {
+      int r = r0 + row[it];
+      if constexpr (!FULL) r = r < nrows ? r : nrows - 1;
+      char* dst = buf + (it * NT + wu * 64) * 16;   // wave-uniform; the hardware adds lane * 16
+      dma16(xb + (int64_t)r * rsx + col[it], lds_addr(dst));
+      dma16(yb + (int64_t)r * rsy + col[it], lds_addr(dst + RT::BYTES));
+    }
+  }
+};
+
 __device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* p, bool valid) {
   u32x4_t v = {0, 0, 0, 0};
   if (valid) v = *(const u32x4_t*)p;
@@ -412,11 +447,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
                                                             const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
                                                             float sc, float scale, int nkb) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES + 2 * 64 * 4];
-  char* q_lds = smem;
-  char* do_lds = smem + RowTile<HDP>::BYTES;
-  float* lse_s = (float*)(smem + 2 * RowTile<HDP>::BYTES);
-  float* dl_s = lse_s + 64;
+  // two {Q, dO} images filled by LDS-DMA (tile t+1 lands while tile t is multiplied) + two {lse, delta} rows; one
+  // barrier per tile
+  constexpr int BUFB = 2 * RowTile<HDP>::BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUFB + 2 * 2 * 64 * 4];
+  float* stat = (float*)(smem + 2 * BUFB);   // [buffer][lse 0..63 | delta 0..63]
   const TrFrag<HDP> trf(threadIdx.x & 63);
   constexpr int KS = HDP / 32, DT = HDP / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -449,31 +484,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
     dkacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
 
-  u32x4_t qreg[RowTile<HDP>::NIT], doreg[RowTile<HDP>::NIT];
   float lse_r = 0.f, dl_r = 0.f;
   const f32x2_t sc2 = {sc, sc};
   const int nt = (S + 63) / 64;
-  auto load_tile = [&](int r0) {
-    RowTile<HDP>::load(qbase, rs, r0, S, hd, tid, qreg);
-    RowTile<HDP>::load(dobase, os, r0, S, hd, tid, doreg);
+  const TileDma<HDP, 256> dma(tid, hd);
+  auto load_stats = [&](int r0) {
     if (tid < 64) {
       const int q = r0 + tid;
-      lse_r = q < S ? lse_b[q] : INFINITY;  // +inf -> P = 0 for padded query rows
+      lse_r = q < S ? lse_b[q] : INFINITY;  // +inf -> P = 0 for padded query rows (their Q / dO rows re-read row S-1)
       dl_r = q < S ? dl_b[q] : 0.f;
     }
   };
-  load_tile(0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // compiler-visible vmcnt(0): the K / V fragment loads are complete
+  load_stats(0);
+  dma.template issue<false>(qbase, rs, dobase, os, 0, S, smem);
+  if (tid < 64) {
+    stat[tid] = lse_r;
+    stat[64 + tid] = dl_r;
+  }
+  if (nt > 1) load_stats(64);
 
   for (int t = 0; t < nt; t++) {
-    __syncthreads();
-    RowTile<HDP>::store(q_lds, tid, qreg);
-    RowTile<HDP>::store(do_lds, tid, doreg);
-    if (tid < 64) {
-      lse_s[tid] = lse_r;
-      dl_s[tid] = dl_r;
+    char* q_lds = smem + (t & 1) * BUFB;
+    char* do_lds = q_lds + RowTile<HDP>::BYTES;
+    const float* lse_s = stat + (t & 1) * 128;
+    const float* dl_s = lse_s + 64;
+    // this wave's part of tile t (and the statistics registers of tile t+1) has landed; the barrier publishes every
+    // wave's part and the statistics row written an iteration ago, and frees the other buffers
+    wait_vmcnt<0>();
+    raw_barrier();
+    if (t + 1 < nt) {
+      if (tid < 64) {
+        stat[((t + 1) & 1) * 128 + tid] = lse_r;
+        stat[((t + 1) & 1) * 128 + 64 + tid] = dl_r;
+      }
+      if (t + 2 < nt) load_stats((t + 2) * 64);
+      if ((t + 1) * 64 + 64 <= S) dma.template issue<true>(qbase, rs, dobase, os, (t + 1) * 64, S, smem + ((t + 1) & 1) * BUFB);
+      else dma.template issue<false>(qbase, rs, dobase, os, (t + 1) * 64, S, smem + ((t + 1) & 1) * BUFB);
     }
-    __syncthreads();
-    if (t + 1 < nt) load_tile((t + 1) * 64);
 
     float pv[4][4], dsv[4][4];
 #pragma unroll
@@ -555,9 +603,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           const float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
                                                           float sc, float scale, int nqb) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * RowTile<HDP>::BYTES];
-  char* k_lds = smem;
-  char* v_lds = smem + RowTile<HDP>::BYTES;
+  // {K,V} x NBUF ring filled by LDS-DMA (see the forward kernel): one barrier per tile, tile t+DIST in flight
+  constexpr int NBUF = HDP <= 64 ? 3 : 2, DIST = NBUF - 1, BUFB = 2 * RowTile<HDP>::BYTES, RINGB = NBUF * BUFB;
+  __shared__ __attribute__((aligned(16))) char smem[RINGB];
   const TrFrag<HDP> trf(threadIdx.x & 63);
   constexpr int KS = HDP / 32, DT = HDP / 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -593,22 +641,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) dqacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  u32x4_t kreg[RowTile<HDP>::NIT], vreg[RowTile<HDP>::NIT];
   const f32x2_t sc2 = {sc, sc};
   const int nt = (S + 63) / 64;
-  RowTile<HDP>::load(kbase, rs, 0, S, hd, tid, kreg);
-  RowTile<HDP>::load(vbase, rs, 0, S, hd, tid, vreg);
+  const TileDma<HDP, 256> dma(tid, hd);
+  constexpr int NDMA2 = 2 * TileDma<HDP, 256>::NDMA;   // DMA instructions per wave per tile
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // compiler-visible vmcnt(0): the Q / dO / lse loads above are complete
+#pragma unroll
+  for (int d = 0; d < DIST; d++)
+    if (d < nt) dma.template issue<false>(kbase, rs, vbase, rs, d * 64, S, smem + d * BUFB);
+  int cur_off = 0, nxt_off = DIST * BUFB;
 
   for (int t = 0; t < nt; t++) {
     const int k0 = t * 64;
-    __syncthreads();
-    RowTile<HDP>::store(k_lds, tid, kreg);
-    RowTile<HDP>::store(v_lds, tid, vreg);
-    __syncthreads();
-    if (t + 1 < nt) {
-      RowTile<HDP>::load(kbase, rs, k0 + 64, S, hd, tid, kreg);
-      RowTile<HDP>::load(vbase, rs, k0 + 64, S, hd, tid, vreg);
+    char* k_lds = smem + cur_off;
+    char* v_lds = k_lds + RowTile<HDP>::BYTES;
+    if (DIST >= 2 && t + 1 < nt) wait_vmcnt<NDMA2>();
+    else wait_vmcnt<0>();
+    raw_barrier();
+    if (t + DIST < nt) {
+      if ((t + DIST) * 64 + 64 <= S) dma.template issue<true>(kbase, rs, vbase, rs, (t + DIST) * 64, S, smem + nxt_off);
+      else dma.template issue<false>(kbase, rs, vbase, rs, (t + DIST) * 64, S, smem + nxt_off);
     }
+    cur_off = cur_off + BUFB == RINGB ? 0 : cur_off + BUFB;
+    nxt_off = nxt_off + BUFB == RINGB ? 0 : nxt_off + BUFB;
     f32x4_t sacc[2][4], dpacc[2][4];
 #pragma unroll
     for (int qt = 0; qt < 2; qt++)
@@ -641,7 +696,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
           const f32x2_t dpv = {dpacc[qt][kt][2 * hf], dpacc[qt][kt][2 * hf + 1]};
           const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl);
           const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          const f32x2_t ds = e * (dpv - dl2);
+          f32x2_t ds = e * (dpv - dl2);
+          if (k0 + 64 > S) {   // wave-uniform: padded keys of the last tile re-read key S-1, their dS must vanish
+            const int key = k0 + kt * 16 + 4 * g + 2 * hf;
+            if (key >= S) ds[0] = 0.f;
+            if (key + 1 >= S) ds[1] = 0.f;
+          }
           sacc[qt][kt][2 * hf] = ds[0];
           sacc[qt][kt][2 * hf + 1] = ds[1];
         }

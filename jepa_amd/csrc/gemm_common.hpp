@@ -149,10 +149,14 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 // swizzled by (row >> 1) & 7: conflict-free reads, 2-way writes that hide under the ds_write data transfer) and reads
 // it back row-major: one ds_read_b128 + one 16-byte store per lane, eight complete 128-byte lines per instruction.
 // The arithmetic (bias, residual, GELU) stays in the MFMA layout and is identical to gemm_epilogue_impl.
-template <int EPI, bool HAS_OPT, bool EDGE>
+template <int EPI, bool HAS_OPT, bool EDGE, int IPP>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage) {
+  // IPP = 16-row blocks per pass: 8 -> the whole wave tile in one 16 KB pass (stage = 16 KB per wave, the dead operand
+  // ring of the one-tile-per-workgroup kernel); 2 -> four 4 KB passes (persistent kernel: the ring already holds the
+  // next tile's first parts, the staging area is a separate 32 KB).
   static_assert(EPI != EPI_F32, "fp32 outputs are stored directly");
+  static_assert(IPP == 8 || IPP == 2, "passes of 128 or 32 rows");
   constexpr int FM = 8, FN = 4;
   const int64_t ncol0 = n_base + fg * 4;
   int64_t ncl[FN];
@@ -183,11 +187,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
   for (int par = 0; par < 2; par++) rd_off[par] = rrow * 128 + ((rch ^ ((par * 4 + (rrow >> 1)) & 7)) << 4);
   const bool col_ok = !EDGE || (n_base + rch * 8 < p.N);
 
-  auto flush = [&](bf16_t* out, int64_t ld) {   // LDS image -> global, 16 x (ds_read_b128 + 16-byte store)
+  auto flush = [&](bf16_t* out, int64_t ld, int row0) {   // LDS image -> global: (ds_read_b128 + 16-byte store) per 8 rows
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
+    for (int it = 0; it < IPP * 2; it++) {
       const u32x4_t v = *(const u32x4_t*)(stage + it * 1024 + rd_off[it & 1]);
-      const int64_t m = m_base + it * 8 + rrow;
+      const int64_t m = m_base + row0 + it * 8 + rrow;
       if (col_ok && (!EDGE || m < p.M)) *(u32x4_t*)(out + m * ld + n_base + rch * 8) = v;
     }
   };
@@ -205,59 +209,63 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     for (int j = 0; j < FN; j++) dst[j] = *(const u32x2_t*)(base + ncl[j]);
   };
   if constexpr (HAS_OPND) load_row(0, opnd[0]);
-  u32x2_t second[TWO_OUT ? FM : 1][FN];   // GELU outputs wait here (packed bf16) while the pre-activations go out
 #pragma unroll
-  for (int i = 0; i < FM; i++) {
-    if constexpr (HAS_OPND) {
-      if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
-    }
+  for (int ps = 0; ps < FM / IPP; ps++) {
+    u32x2_t second[TWO_OUT ? IPP : 1][FN];   // GELU outputs wait here (packed bf16) while the pre-activations go out
 #pragma unroll
-    for (int j = 0; j < FN; j++) {
-      f32x2_t v01 = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y};
-      f32x2_t v23 = {acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
-      u32x2_t o;
-      if constexpr (EPI == EPI_GELU) {
-        u32x2_t u;
-        u[0] = pack_bf2(v01[0], v01[1]);
-        u[1] = pack_bf2(v23[0], v23[1]);
-        // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
-        v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
-        v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
-        o[0] = pack_bf2(v01[0], v01[1]);
-        o[1] = pack_bf2(v23[0], v23[1]);
-        if constexpr (TWO_OUT) {
-          second[i][j] = o;
-          o = u;
-        }
-      } else {
-        if constexpr (EPI == EPI_DGELU) {
-          const u32x2_t u = opnd[i & 1][j];
-          v01 *= dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
-          v23 *= dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
-        } else if constexpr (HAS_OPT) {
-          const u32x2_t r2 = opnd[i & 1][j];
-          v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
-          v23 += (f32x2_t){bf_lo(r2[1]), bf_hi(r2[1])};
-        }
-        o[0] = pack_bf2(v01[0], v01[1]);
-        o[1] = pack_bf2(v23[0], v23[1]);
+    for (int ii = 0; ii < IPP; ii++) {
+      const int i = ps * IPP + ii;
+      if constexpr (HAS_OPND) {
+        if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
       }
-      *(u32x2_t*)(stage + i * 2048 + wr_off[j]) = o;
+#pragma unroll
+      for (int j = 0; j < FN; j++) {
+        f32x2_t v01 = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y};
+        f32x2_t v23 = {acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+        u32x2_t o;
+        if constexpr (EPI == EPI_GELU) {
+          u32x2_t u;
+          u[0] = pack_bf2(v01[0], v01[1]);
+          u[1] = pack_bf2(v23[0], v23[1]);
+          // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
+          v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+          v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
+          o[0] = pack_bf2(v01[0], v01[1]);
+          o[1] = pack_bf2(v23[0], v23[1]);
+          if constexpr (TWO_OUT) {
+            second[ii][j] = o;
+            o = u;
+          }
+        } else {
+          if constexpr (EPI == EPI_DGELU) {
+            const u32x2_t u = opnd[i & 1][j];
+            v01 *= dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+            v23 *= dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
+          } else if constexpr (HAS_OPT) {
+            const u32x2_t r2 = opnd[i & 1][j];
+            v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
+            v23 += (f32x2_t){bf_lo(r2[1]), bf_hi(r2[1])};
+          }
+          o[0] = pack_bf2(v01[0], v01[1]);
+          o[1] = pack_bf2(v23[0], v23[1]);
+        }
+        *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = o;
+      }
     }
-  }
-  if constexpr (TWO_OUT) {
-    flush(p.aux_out, p.ldaux);
+    if constexpr (TWO_OUT) {
+      flush(p.aux_out, p.ldaux, ps * IPP * 16);
 #pragma unroll
-    for (int i = 0; i < FM; i++)
+      for (int ii = 0; ii < IPP; ii++)
 #pragma unroll
-      for (int j = 0; j < FN; j++) *(u32x2_t*)(stage + i * 2048 + wr_off[j]) = second[i][j];
+        for (int j = 0; j < FN; j++) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = second[ii][j];
+    }
+    flush((bf16_t*)p.C, p.ldc, ps * IPP * 16);
   }
-  flush((bf16_t*)p.C, p.ldc);
 }
 
 // staged variant selector for the 8-phase kernel (wave tile 128 x 64); falls back to the direct form when the 16-byte
 // row-major stores cannot be used (N, ldc or the base pointers not 8-element aligned) and for fp32 outputs
-template <int EPI>
+template <int EPI, int IPP = 8>
 __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                          int64_t n_base, int frow, int fg, int lane, char* stage) {
   if constexpr (EPI == EPI_F32) {
@@ -272,11 +280,11 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     else opt = true;
     const bool edge = __builtin_amdgcn_readfirstlane((m_base + 128 > p.M) || (n_base + 64 > p.N));
     if (opt) {
-      if (edge) gemm_epilogue_staged<EPI, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-      else gemm_epilogue_staged<EPI, true, false>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      else gemm_epilogue_staged<EPI, true, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
     } else if constexpr (EPI != EPI_DGELU) {
-      if (edge) gemm_epilogue_staged<EPI, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-      else gemm_epilogue_staged<EPI, false, false>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      if (edge) gemm_epilogue_staged<EPI, false, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      else gemm_epilogue_staged<EPI, false, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
     }
     return true;
   }
