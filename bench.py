@@ -270,7 +270,7 @@ def main():
             with open(pmc) as fjs:
                 ent = json.load(fjs).get("gemm_nt_8phase_kernel<0>")
             if ent:
-                traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r01_c_hbm_pmc.md"
+                traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r01_d_hbm_pmc.md"
         roof = {"bound": "mfma",
                 "kernel": "bf16 MFMA GEMM family (gemm_nt_8phase_kernel 256x256 staggered 8-phase + gemm_nt_kernel "
                           "128x128 split-K wgrads; MFMA 16x16x32, LDS-DMA staged)",

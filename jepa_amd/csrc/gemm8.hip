@@ -91,15 +91,6 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
   const int nk = (kt0 + p.ktiles_per < nk_all ? kt0 + p.ktiles_per : nk_all) - kt0;
   const int last_part = 4 * nk - 2;   // parts: -1 (A0 of tile 0), then per tile B0, B1, A1 and A0 of the next tile
 
-  // Start-up skew.  All workgroups of a round finish their K loop together, and the 256 simultaneous 128 KB epilogue
-  // bursts (33 MB) then drain at the fabric's write rate for 7-9 us while every MFMA idles (tools/gemm_ksweep.py:
-  // 12 us fixed cost per tile round with the stores, 3-5 us without).  Delaying the first-round workgroups by up to
-  // ~skew_us spreads the epilogues of every following round in time.  dbg bits 8.. = skew step in units of 64 clocks.
-  if (p.skew_step > 0 && blockIdx.x < 256) {
-    const int steps = (blockIdx.x >> 3) & 7;   // XCD = blockIdx % 8: the CUs of one XCD get 8 different delays
-    for (int i = 0; i < steps * p.skew_step; i++) __builtin_amdgcn_s_sleep(1);
-  }
-
   f32x4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; i++)

@@ -18,8 +18,7 @@ struct GemmArgs {
   int splitk;          // > 1: K is cut into `splitk` slices, raw fp32 partials go to ws[slice][M][N] (EPI_F32 only)
   int ktiles_per;      // K-tiles per slice
   float* ws;
-  int skew_step;       // first-round start-up skew: step in units of 64 clocks per delay slot (0 = off), gemm8.hip
-  int dbg;             // diagnostics (VJ_GEMM_DBG): bit0 = skip the epilogue stores, bit1 = 16-byte stores
+  int dbg;             // diagnostics (env VJ_GEMM_DBG, tools/gemm_ksweep.py): bit0 = drop the epilogue, bit1 = direct (unstaged) stores
 };
 
 
