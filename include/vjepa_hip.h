@@ -82,6 +82,14 @@ int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void
 int vj_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                            int64_t N, int64_t K, float alpha, float beta, int flags, void* ws, int64_t ws_bytes,
                            vj_stream_t stream);
+/* weight gradient WITHOUT operand transposes (autograd of nn.Linear, modules.py:31-34,63,76):
+ *   dW[N1,N2] (fp32) = alpha * dY[T,N1]^T * X[T,N2] + beta * dW,   T = tokens (any positive count; the last 64-token
+ * tile is completed with zero rows inside the kernel).  Both operands are read row-major as the backward pass left
+ * them; N1 % 8 == 0, N2 % 8 == 0, ldy/ldx % 8 == 0 and < 2^24, 16-byte aligned bases; split-K over the tokens as
+ * above (ws_bytes >= N1*N2*4). */
+int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int64_t T,
+                           int64_t N1, int64_t N2, float alpha, float beta, void* ws, int64_t ws_bytes,
+                           vj_stream_t stream);
 /* out[N, Mpad] = in[M,N]^T (zero padded): the wgrad operands dY^T, X^T; weight shadows W^T for dgrad. */
 int vj_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,
                       vj_stream_t stream);

@@ -320,6 +320,7 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.tiles_m = a.tiles_n = 0; a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
   static const int dbg_env = [] { const char* e = getenv("VJ_GEMM_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg_env;
+  a.zero_row = nullptr;
   switch (epilogue) {
     case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, nullptr, 0, stream);
     case EPI_GELU: return dispatch_gemm<EPI_GELU>(a, flags, nullptr, 0, stream);

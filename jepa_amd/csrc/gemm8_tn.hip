@@ -1,0 +1,318 @@
+// Weight-gradient GEMM without operand transposes:  dW[N1,N2] (fp32) = alpha * dY[T,N1]^T X[T,N2] + beta * dW
+//
+// Replaces the "transpose dY, transpose X, then C = A B^T" route for every nn.Linear weight gradient of the V-JEPA step
+// (reference: autograd of nn.Linear, modules.py:31-34,63,76; the optimizer reads these fp32 gradients, train.py:461-476).
+// Both operands are read exactly as the backward pass produced them -- row = token, columns = features -- so the
+// contraction index (the token) is the SLOW dimension of both.  gfx950's ds_read_b64_tr_b16 delivers an MFMA operand
+// fragment whose k index runs down the rows of a row-major LDS image, which makes this layout free:
+//
+//   * same schedule as gemm8.hip (256 x 256 tile, 8 waves, four 16 KB parts per 64-token K-tile in an 8-slot LDS ring,
+//     prefetch distance 4 parts, counted vmcnt across raw barriers, two wave groups one barrier interval apart);
+//   * a part is 64 tokens x 128 feature columns (256-byte rows).  Part A0/A1 = columns [0,128) / [128,256) of the dY
+//     tile, B0/B1 the same of the X tile; wave (wm, wn) owns output rows {wm*64 + [0,64)} of each A half and columns
+//     {wn*32 + [0,32)} of each B half, i.e. four 64 x 32 quadrants (acc[ih][jh]);
+//   * 16-byte chunk c of token row r sits at chunk c ^ ((r & 7) << 1): the DMA destination is lane-linear, so the
+//     swizzle is applied to the per-lane SOURCE column; the transpose read of a lane group (8 token rows x 32 bytes)
+//     then touches all 64 banks once;
+//   * a fragment = two transpose reads (token rows 4g..4g+3 and 16+4g..16+4g+3 of a 32-token step).  The k-slot ->
+//     token map differs from a plain row read but is the same for both operands, which is all a dot product needs;
+//   * tokens beyond T (last K-tile) contribute zero: dY rows are redirected to a zero row (X rows re-read row T-1);
+//   * the LDS-DMA is issued through inline assembly so that the compiler does not put an `s_waitcnt vmcnt(0)` in front
+//     of the transpose reads (it does after the builtin form; see attention.hip).
+//
+// Split-K over the token tiles and the fp32 epilogue are shared with the NT kernels (gemm_common.hpp).
+#include "gemm_common.hpp"
+
+#define TN_PART_BYTES 16384
+
+namespace {
+
+__device__ __forceinline__ void tn_cfence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void tn_bar() {
+  tn_cfence();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  tn_cfence();
+}
+template <int N>
+__device__ __forceinline__ void tn_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ unsigned tn_lds_addr(const char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void tn_dma16(const void* gsrc, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(gsrc) : "memory");
+}
+
+typedef __attribute__((ext_vector_type(4))) short tn_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short tn_s16x8_t;
+
+// fragment: 16 feature columns x 32 tokens, from the part image at `p` (= slot + lane offset + token-step offset)
+__device__ __forceinline__ bf16x8_t tn_frag(const char* p) {
+  const tn_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4_t*)p);
+  const tn_s16x4_t hi =
+      __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tn_s16x4_t*)(p + 16 * 256));
+  const tn_s16x8_t w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+
+struct TnLane {   // per-lane constants of the part image (2 VGPRs live across the K loop)
+  int row0;   // token row of this lane's chunk for j = 0 (0..31); j = 1 is 32 rows further, same chunk
+  int sc8;    // source column (elements) inside the 128-column half: ((tid & 15) ^ ((row0 & 7) << 1)) * 8
+};
+
+// issue the LDS-DMA of part q (q = -1 .. 4*nk-1) into slot (q+8) % 8.  qq = q + 1 = 4T + kind:
+// kind 0 = A0(T), 1 = B0(T), 2 = B1(T), 3 = A1(T)  (A = dY tile, B = X tile, T = token tile).
+// One branch-free form for every tile: uniform base pointer + 32-bit per-lane offset; token rows beyond T are clamped
+// to row T-1 (a valid address) and, for dY, redirected to the zero row so that they contribute nothing.
+__device__ __forceinline__ void tn_issue_part(const GemmArgs& p, int q, int64_t m0, int64_t n0, int kt0, char* smem,
+                                              const TnLane& tl, int wave_u) {
+  const int qq = q + 1;
+  const int kind = qq & 3;
+  const int t = qq >> 2;
+  const int64_t tok0 = (int64_t)(kt0 + t) * 64;
+  char* slot = smem + ((q + 8) & 7) * TN_PART_BYTES;
+  const bool isA = (kind == 0) || (kind == 3);
+  const int half = (kind == 0 || kind == 1) ? 0 : 1;
+  const int64_t cbase = (isA ? m0 : n0) + half * 128;
+  // columns beyond the matrix re-read its last 8 columns (those outputs are never stored); may be negative
+  const int lim = (int)((isA ? p.M : p.N) - cbase - 8);
+  const int rel = tl.sc8 < lim ? tl.sc8 : lim;
+  const unsigned ld = (unsigned)(isA ? p.lda : p.ldb);
+  const bf16_t* base = (isA ? p.A + tok0 * p.lda : p.B + tok0 * p.ldb) + cbase;   // uniform
+  const int64_t left = p.K - 1 - tok0;
+  const int last_row = left < 63 ? (int)left : 63;   // uniform: last existing token row of this tile
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int row = tl.row0 + 32 * j;
+    const int rowc = row < last_row ? row : last_row;
+    const bf16_t* src = base + (int64_t)(int)(__umul24((unsigned)rowc, ld) + rel);
+    if (isA) {
+      const bf16_t* zsrc = p.zero_row + tl.sc8;
+      src = row <= last_row ? src : zsrc;
+    }
+    tn_dma16(src, tn_lds_addr(slot + (j * 512 + wave_u * 64) * 16));
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_u >> 2, wn = wave_u & 3;
+  const bool late_group = wave_u >= 4;
+
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int logical_all = xcd_logical(blockIdx.x, ntile * p.splitk);
+  const int slice = logical_all / ntile;
+  int tm, tn;
+  tile_of(logical_all - slice * ntile, p.tiles_m, p.tiles_n, tm, tn);
+  const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+  const int nk_all = (int)((p.K + 63) / 64);
+  const int kt0 = slice * p.ktiles_per;
+  const int nk = (kt0 + p.ktiles_per < nk_all ? kt0 + p.ktiles_per : nk_all) - kt0;
+  const int last_part = 4 * nk - 2;
+
+  f32x4_t acc[2][2][4][2];   // [row half][column half][16-row block][16-column block]
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[a][b][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t ra0[4][2], ra1[4][2], rb0[2][2], rb1[2][2];   // [fragment][32-token step]
+
+  // transpose-read source of this lane: token row 4g + jj of a 16-row group, 8-byte piece q4 of the 32-byte column run
+  int a_off[4], b_off[2];
+  {
+    const int g = lane >> 4, jj = (lane & 15) >> 2, q4 = lane & 3;
+    const int row_l = 4 * g + jj;
+    const int key2 = (row_l & 7) << 1;
+    const int base = row_l * 256 + (q4 & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) a_off[i] = base + ((((wm * 8 + i * 2) ^ key2) | (q4 >> 1)) << 4);
+#pragma unroll
+    for (int j = 0; j < 2; j++) b_off[j] = base + ((((wn * 4 + j * 2) ^ key2) | (q4 >> 1)) << 4);
+  }
+
+  TnLane tl;
+  tl.row0 = tid >> 4;
+  tl.sc8 = ((tid & 15) ^ (((tid >> 4) & 7) << 1)) * 8;
+
+  // ---- prologue: parts -1 (A0 of tile 0), 0, 1, 2 in flight; part -1 landed for everyone
+  tn_issue_part(p, -1, m0, n0, kt0, smem, tl, wave_u);
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    if (q <= last_part) tn_issue_part(p, q, m0, n0, kt0, smem, tl, wave_u);
+  if (last_part >= 2) tn_wait_vm<6>();
+  else tn_wait_vm<0>();
+  tn_bar();
+  if (late_group) tn_bar();
+  {
+    const char* slot = smem + 7 * TN_PART_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) ra0[i][ks] = tn_frag(slot + a_off[i] + ks * 32 * 256);
+    if (3 <= last_part) tn_issue_part(p, 3, m0, n0, kt0, smem, tl, wave_u);
+    if (3 <= last_part) tn_wait_vm<6>();
+    else tn_wait_vm<0>();
+  }
+  tn_bar();
+  tn_bar();
+
+  for (int t = 0; t < nk; t++) {
+#pragma unroll
+    for (int ph = 0; ph < 4; ph++) {
+      const int q = 4 * t + ph;
+      const char* slot = smem + (q & 7) * TN_PART_BYTES;
+      // ---------------- L(q)
+      if (ph == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++) rb0[j][ks] = tn_frag(slot + b_off[j] + ks * 32 * 256);
+      } else if (ph == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++) rb1[j][ks] = tn_frag(slot + b_off[j] + ks * 32 * 256);
+      } else if (ph == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++) ra1[i][ks] = tn_frag(slot + a_off[i] + ks * 32 * 256);
+      } else if (t + 1 < nk) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++) ra0[i][ks] = tn_frag(slot + a_off[i] + ks * 32 * 256);
+      }
+      if (q + 4 <= last_part) {
+        tn_issue_part(p, q + 4, m0, n0, kt0, smem, tl, wave_u);
+        tn_wait_vm<6>();                              // part q+1 landed; q+2..q+4 in flight
+      } else {
+        const int younger = last_part - (q + 1);
+        if (younger >= 2) tn_wait_vm<4>();
+        else if (younger == 1) tn_wait_vm<2>();
+        else tn_wait_vm<0>();
+      }
+      tn_bar();
+      // ---------------- C(q): one quadrant x 64 tokens
+      __builtin_amdgcn_s_setprio(1);
+      if (ph == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+              acc[0][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb0[j][ks], ra0[i][ks], acc[0][0][i][j], 0, 0, 0);
+      } else if (ph == 1) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+              acc[0][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb1[j][ks], ra0[i][ks], acc[0][1][i][j], 0, 0, 0);
+      } else if (ph == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+              acc[1][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb1[j][ks], ra1[i][ks], acc[1][1][i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+              acc[1][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb0[j][ks], ra1[i][ks], acc[1][0][i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      tn_bar();
+    }
+  }
+  if (!late_group) tn_bar();
+
+  const int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int efrow = elane & 15, efg = elane >> 4;
+#pragma unroll
+  for (int ih = 0; ih < 2; ih++)
+#pragma unroll
+    for (int jh = 0; jh < 2; jh++)
+      gemm_epilogue<EPI_F32, 4, 2, true>(p, acc[ih][jh], m0 + ih * 128 + wm * 64, n0 + jh * 128 + wn * 32, efrow, efg,
+                                         slice);
+}
+
+bf16_t* g_zero_row = nullptr;   // 128 bf16 zeros (one process drives one GPU)
+
+}  // namespace
+
+__global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, int64_t N, int64_t ldc, int S,
+                                     float alpha, float beta);   // gemm.hip
+
+// dW[N1,N2] = alpha * dY[T,N1]^T X[T,N2] + beta * dW.  (backward of every nn.Linear on the path)
+extern "C" int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw,
+                                      int64_t T, int64_t N1, int64_t N2, float alpha, float beta, void* ws,
+                                      int64_t ws_bytes, hipStream_t stream) {
+  VJ_CHECK_ARG(T >= 0 && N1 >= 0 && N2 >= 0, "vj_gemm_bf16_tn_splitk: negative dim");
+  if (N1 == 0 || N2 == 0) return 0;
+  VJ_CHECK_ARG(T > 0, "vj_gemm_bf16_tn_splitk: T must be positive");
+  VJ_CHECK_ARG(N1 % 8 == 0 && N2 % 8 == 0, "vj_gemm_bf16_tn_splitk: N1=%ld, N2=%ld must be multiples of 8", (long)N1,
+               (long)N2);
+  VJ_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N1 && ldx >= N2 && ldy < (1 << 24) && ldx < (1 << 24),
+               "vj_gemm_bf16_tn_splitk: ldy/ldx must be multiples of 8, >= N1/N2 and < 2^24");
+  VJ_CHECK_ARG(((uintptr_t)dY % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)dW % 16 == 0),
+               "vj_gemm_bf16_tn_splitk: operands must be 16-byte aligned");
+  VJ_CHECK_ARG(ldw % 4 == 0 && ldw >= N2, "vj_gemm_bf16_tn_splitk: ldw=%ld must be a multiple of 4 and >= N2", (long)ldw);
+  VJ_CHECK_ARG(ws != nullptr && ws_bytes >= N1 * N2 * 4, "vj_gemm_bf16_tn_splitk: workspace must hold at least N1*N2 fp32");
+  if (g_zero_row == nullptr) {
+    hipError_t e = hipMalloc((void**)&g_zero_row, 256);
+    if (e == hipSuccess) e = hipMemset(g_zero_row, 0, 256);
+    if (e != hipSuccess) {
+      vj_set_error("vj_gemm_bf16_tn_splitk: zero row allocation failed: %s", hipGetErrorString(e));
+      g_zero_row = nullptr;
+      return (int)e;
+    }
+  }
+  constexpr int smem = 8 * TN_PART_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_8phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  GemmArgs b;
+  b.A = (const bf16_t*)dY; b.B = (const bf16_t*)X; b.C = dW; b.bias = nullptr; b.res = nullptr; b.aux_in = nullptr;
+  b.aux_out = nullptr;
+  b.M = N1; b.N = N2; b.K = T; b.lda = ldy; b.ldb = ldx; b.ldc = ldw; b.ldr = 0; b.ldaux = 0;
+  b.alpha = alpha; b.beta = beta;
+  b.tiles_m = (int)cdiv64(N1, 256);
+  b.tiles_n = (int)cdiv64(N2, 256);
+  b.dbg = 0;
+  b.zero_row = g_zero_row;
+  const int nk = (int)cdiv64(T, 64);
+  b.splitk = pick_splitk((int64_t)b.tiles_m * b.tiles_n, nk, 256, 1.45, 8, N1, N2, ws_bytes);
+  b.ws = (float*)ws;
+  b.ktiles_per = (nk + b.splitk - 1) / b.splitk;
+  b.splitk = (nk + b.ktiles_per - 1) / b.ktiles_per;
+  hipLaunchKernelGGL(gemm_tn_8phase_kernel, dim3(b.tiles_m * b.tiles_n * b.splitk), dim3(512), smem, stream, b);
+  VJ_LAUNCH_CHECK("vj_gemm_bf16_tn_splitk");
+  if (b.splitk > 1) {
+    const int64_t n4 = N1 * N2 / 4;
+    int64_t g = cdiv64(n4, 256);
+    if (g > 256 * 8) g = 256 * 8;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float4*)b.ws, dW, N1, N2, ldw,
+                       b.splitk, alpha, beta);
+    VJ_LAUNCH_CHECK("vj_gemm_bf16_tn_splitk(reduce)");
+  }
+  return 0;
+}

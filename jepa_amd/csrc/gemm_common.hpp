@@ -18,6 +18,7 @@ struct GemmArgs {
   int splitk;          // > 1: K is cut into `splitk` slices, raw fp32 partials go to ws[slice][M][N] (EPI_F32 only)
   int ktiles_per;      // K-tiles per slice
   float* ws;
+  const bf16_t* zero_row;   // 128 bf16 zeros: source of token rows beyond T in the TN weight-gradient kernel (gemm8_tn.hip)
   int dbg;             // diagnostics (env VJ_GEMM_DBG, tools/gemm_ksweep.py): bit0 = drop the epilogue, bit1 = direct (unstaged) stores
 };
 

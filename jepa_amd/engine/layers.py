@@ -12,6 +12,7 @@ Reference semantics restated (never copied):
   VisionTransformerPredictor     src/models/predictor.py:174-239
   MultiMask wrappers             src/models/utils/multimask.py:11-48
 """
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -92,7 +93,26 @@ def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
     return x2, saved
 
 
+# Transpose-free weight gradients (vj_gemm_bf16_tn_splitk) are numerically equivalent and remove every activation
+# transpose, but on MI355X the step time is the same (277.4 vs 278.0 clips/s, same box): with 2 waves per SIMD the 8-byte
+# transpose reads run well below the LDS peak and the TN K loop is ~30 % slower than the NT one -- exactly what the
+# transposes cost.  Default: the NT route (the one profiled in profiles/); VJ_WGRAD_TN=1 selects the TN route.
+WGRAD_TN = os.environ.get("VJ_WGRAD_TN", "0") == "1"
+
+
+def _tn_ok(n_out: int, k_in: int) -> bool:
+    """The transpose-free weight-gradient kernel works on 256 x 256 output tiles: use it where they are (nearly) full."""
+    def waste(n):
+        return ((n + 255) // 256 * 256) / n
+    return WGRAD_TN and n_out % 8 == 0 and k_in % 8 == 0 and waste(n_out) * waste(k_in) <= 1.10
+
+
 def _wgrad(dy, x_in, lw: LinearW, alpha: float):
+    if _tn_ok(dy.shape[1], x_in.shape[1]):
+        if lw.gb is not None:
+            ops.colsum(dy, lw.gb, alpha=alpha)
+        ops.gemm_wgrad_tn(dy, x_in, lw.gw, alpha=alpha)
+        return
     dyT = ops.transpose_colsum(dy, lw.gb, alpha=alpha) if lw.gb is not None else ops.transpose(dy)
     xT = ops.transpose(x_in)
     ops.gemm_wgrad(dyT, xT, lw.gw, alpha=alpha)

@@ -207,6 +207,22 @@ def gemm_wgrad(dyT, xT, out, alpha=1.0, beta=0.0, flags=None, stream=None):
     return out
 
 
+def gemm_wgrad_tn(dy, x, out, alpha=1.0, beta=0.0, stream=None):
+    """out[N_out, K_in] (fp32) = alpha * dy[T, N_out]^T @ x[T, K_in] + beta*out: no operand transposes, split-K over T."""
+    lib = load_library()
+    _req(dy, BF16, "dy")
+    _req(x, BF16, "x")
+    T, N1 = dy.shape
+    N2 = x.shape[1]
+    ws = Scratch.get(WGRAD_WS_BYTES, dy.device, "wgrad")
+    _ev = _timed("gemm_nt", 2.0 * T * N1 * N2)
+    check(lib.vj_gemm_bf16_tn_splitk(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(out), out.stride(0), T, N1, N2,
+                                     alpha, beta, _ptr(ws), WGRAD_WS_BYTES, _stream(stream)), "vj_gemm_bf16_tn_splitk")
+    if _ev is not None:
+        _ev.record()
+    return out
+
+
 def transpose_colsum(x, colsum_out, alpha=1.0, accumulate=False, stream=None):
     """x [M,N] bf16 -> x^T [N, pad64(M)] and colsum_out[n] = alpha*sum_m x[m,n] (+ old) in one pass."""
     lib = load_library()

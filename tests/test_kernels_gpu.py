@@ -189,6 +189,25 @@ def test_gemm_gelu_epilogues(ops, M, N, K):
     assert rel_l2(d, d_ref) < 5e-3, rel_l2(d, d_ref)
 
 
+@pytest.mark.parametrize("T,N1,N2", [(473, 1024, 1024), (11392, 3072, 1024), (1000, 520, 776), (66, 256, 256),
+                                     (64, 8, 264), (4099, 1024, 4096)])
+def test_gemm_wgrad_tn_without_transposes(ops, T, N1, N2):
+    """dW[N1,N2] = alpha * dY[T,N1]^T X[T,N2] + beta * dW straight from the row-major operands (transpose reads in LDS,
+    zero rows for the last partial 64-token tile, split-K over the tokens) vs fp32 torch and vs the transpose route."""
+    g = torch.Generator().manual_seed(31)
+    dY = bf(torch.randn(T, N1, generator=g)).to(DEV)
+    X = bf(torch.randn(T, N2, generator=g)).to(DEV)
+    out = torch.full((N1, N2), 1.0, device=DEV)
+    ops.gemm_wgrad_tn(dY, X, out, alpha=0.5, beta=2.0)
+    ref = 0.5 * (dY.float().t() @ X.float()) + 2.0
+    assert rel_l2(out, ref) < 1e-5, rel_l2(out, ref)
+    out2 = torch.empty((N1, N2), device=DEV)
+    ops.gemm_wgrad_tn(dY, X, out2, alpha=0.25)
+    via_t = torch.empty((N1, N2), device=DEV)
+    ops.gemm_wgrad(ops.transpose(dY), ops.transpose(X), via_t, alpha=0.25)
+    assert rel_l2(out2, via_t) < 2e-6, rel_l2(out2, via_t)
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 384, 473), (3072, 1024, 1000), (96, 288, 66)])
 def test_gemm_wgrad_fp32_via_transposes(ops, M, N, K):
     """dW[M=N_out, N=K_in] = dY^T X with K = tokens (padded to 64 by the transpose kernel)."""
