@@ -685,6 +685,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         }
       }
     bf16x8_t dsf[2][2];
+    // dS^T = P^T (dP^T - delta)
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
       const f32x2_t nl = {-lse_q[qt], -lse_q[qt]}, dl2 = {dl_q[qt], dl_q[qt]};
@@ -696,15 +697,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
           const f32x2_t dpv = {dpacc[qt][kt][2 * hf], dpacc[qt][kt][2 * hf + 1]};
           const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl);
           const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          f32x2_t ds = e * (dpv - dl2);
-          if (k0 + 64 > S) {   // wave-uniform: padded keys of the last tile re-read key S-1, their dS must vanish
-            const int key = k0 + kt * 16 + 4 * g + 2 * hf;
-            if (key >= S) ds[0] = 0.f;
-            if (key + 1 >= S) ds[1] = 0.f;
-          }
+          const f32x2_t ds = e * (dpv - dl2);
           sacc[qt][kt][2 * hf] = ds[0];
           sacc[qt][kt][2 * hf + 1] = ds[1];
         }
+    }
+    if (k0 + 64 > S) {   // wave-uniform, last tile only: padded keys re-read key S-1, their dS must vanish
+      asm volatile("" ::: "memory");   // keeps this a real branch (the kernel is VALU-bound; an if-converted mask costs ~30 %)
+#pragma unroll
+      for (int qt = 0; qt < 2; qt++)
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (k0 + kt * 16 + 4 * g + r >= S) sacc[qt][kt][r] = 0.f;
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; qt++) {
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         u32x4_t dw;
