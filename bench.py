@@ -36,9 +36,17 @@ WORKLOADS = {
     "vitl16": dict(model_name="vit_large", crop=224, frames=16, patch=16, tubelet=2, pred_depth=12, pred_dim=384,
                    batch=24, embed_dim=1024, depth=24, masks=VITL_MASKS,
                    desc="V-JEPA pretrain step ViT-L/16 16x224x224, B=24/GPU, 2 multiblock masks (vitl16.yaml)"),
+    # BASELINE.json configs[3]: global batch 3072 over 8 GPUs = 384 clips per GPU, walked in micro-batches of 24 inside
+    # the step (gradient accumulation; the collator still draws masks for all 384)
     "vith16": dict(model_name="vit_huge", crop=224, frames=16, patch=16, tubelet=2, pred_depth=12, pred_dim=384,
-                   batch=24, embed_dim=1280, depth=32, masks=VITL_MASKS,
-                   desc="V-JEPA pretrain step ViT-H/16 16x224x224, B=24/GPU, 2 multiblock masks"),
+                   batch=384, micro_batch=24, embed_dim=1280, depth=32, masks=VITL_MASKS, distinct_batches=2,
+                   desc="V-JEPA pretrain step ViT-H/16 16x224x224, B=384/GPU in micro-batches of 24, 2 multiblock "
+                        "masks (vith16.yaml, global batch 3072 at dp8)"),
+    # BASELINE.json configs[4]: configs/pretrain/vith16_384.yaml (batch_size 10, crop 384 -> 8x24x24 = 4608 tokens)
+    "vith16_384": dict(model_name="vit_huge", crop=384, frames=16, patch=16, tubelet=2, pred_depth=12, pred_dim=384,
+                       batch=10, embed_dim=1280, depth=32, masks=VITL_MASKS, distinct_batches=4,
+                       desc="V-JEPA pretrain step ViT-H/16 16x384x384 (4608 tokens), B=10/GPU, 2 multiblock masks "
+                            "(vith16_384.yaml)"),
     "vittiny": dict(model_name="vit_tiny", crop=64, frames=8, patch=16, tubelet=2, pred_depth=2, pred_dim=96,
                     batch=2, embed_dim=192, depth=12, masks=VITL_MASKS[:1],
                     desc="V-JEPA pretrain step ViT-Tiny/16 8x64x64, B=2, 1 mask (plumbing config)"),
@@ -65,23 +73,28 @@ def build(wl, device, world_size):
         start_lr=HP["start_lr"], ref_lr=HP["lr"], final_lr=HP["final_lr"], iterations_per_epoch=HP["ipe"],
         warmup=HP["warmup"], num_epochs=HP["epochs"], ipe_scale=HP["ipe_scale"], mixed_precision=True,
         betas=HP["betas"], eps=HP["eps"], loss_exp=HP["loss_exp"], reg_coeff=HP["reg_coeff"], clip_grad=10.0,
-        world_size=world_size, device=device)
+        world_size=world_size, device=device, micro_batch=wl.get("micro_batch"))
     return trainer, sched, wd_sched
 
 
-def make_inputs(wl, n_steps, rank, device):
+def make_inputs(wl, n_steps, rank, device, host=False):
+    """Synthetic batches resident in HBM (host=True: in pinned host memory, for the --h2d input-edge run).  Large
+    workloads keep only `distinct_batches` different batches and cycle through them."""
     from jepa_amd.src.masks.multiblock3d import MaskCollator
     coll = MaskCollator(cfgs_mask=wl["masks"], crop_size=wl["crop"], num_frames=wl["frames"],
                         patch_size=wl["patch"], tubelet_size=wl["tubelet"])
     B = wl["batch"]
     batches = []
     gen = torch.Generator(device=device)
-    for step in range(n_steps):
+    for step in range(min(n_steps, wl.get("distinct_batches", n_steps))):
         gen.manual_seed(1234 + step + 1000 * rank)
         clips = torch.randn(B, 3, wl["frames"], wl["crop"], wl["crop"], device=device, generator=gen)  # never zeros
         torch.manual_seed(4321 + step + 1000 * rank)
         _, me, mp = coll([(torch.zeros(1), 0) for _ in range(B)])
-        batches.append((clips, [m.to(device) for m in me], [m.to(device) for m in mp]))
+        if host:
+            batches.append((clips.cpu().pin_memory(), [m.pin_memory() for m in me], [m.pin_memory() for m in mp]))
+        else:
+            batches.append((clips, [m.to(device) for m in me], [m.to(device) for m in mp]))
     return batches
 
 
@@ -128,7 +141,7 @@ def cpu_baseline(wl_name):
     gens = O.make_mask_gens(wl["masks"], wl["crop"], wl["frames"], wl["patch"], wl["tubelet"])
     hp = dict(HP)
     times = []
-    n_timed = 2 if wl_name != "vittiny" else 10
+    n_timed = 3 if wl_name != "vittiny" else 10
     log(f"cpu baseline: model built, {cores} threads")
     for step in range(1, 2 + n_timed):
         clips = torch.randn(B, 3, wl["frames"], wl["crop"], wl["crop"], generator=torch.Generator().manual_seed(step))
@@ -154,6 +167,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (default: the recipe's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--h2d", action="store_true",
+                    help="input-edge run: batches start in pinned HOST memory and go through the double-buffered "
+                         "prefetcher (engine/input.py); reported on stderr, never as `value`")
+    ap.add_argument("--gemm-csv", default=None, help="write one line per GEMM / attention launch of the roofline pass")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -181,6 +198,8 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["batch"] = args.batch
+        if wl.get("micro_batch") and wl["micro_batch"] >= args.batch:
+            wl["micro_batch"] = None
     log(f"building {wl['model_name']} (CPU init, seed 0) ...")
     trainer, sched, wd_sched = build(wl, device, world)
     log("trainer ready; generating synthetic inputs")
@@ -195,6 +214,10 @@ def main():
     def run(i):
         clips, me, mp = batches[i % len(batches)]
         return trainer.train_step(clips, me, mp, lr=sched.step(), wd=wd_sched.step(), ema=mom[i])
+
+    if world > 1 or trainer.reducer.enabled:
+        log(f"data parallel: {torch.distributed.get_world_size()} RCCL rank(s), "
+            f"{len(trainer.reducer.buckets)} layer buckets + {len(trainer.reducer.tail)} tail range(s)")
 
     def sync():
         torch.cuda.synchronize()
@@ -214,6 +237,11 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     log(f"host enqueue time {1e3 * host_enqueue / args.steps:.1f} ms/step (GPU step {1e3 * elapsed / args.steps:.1f} ms)")
+    if trainer.reducer.enabled:   # self-diagnosis of the scaling run: how long the compute stream waited on RCCL
+        ex = trainer.reducer.exposed_ms()
+        if ex is not None:
+            log(f"exposed communication (compute stream blocked in reducer.finish): {ex:.2f} ms/step over the last "
+                f"{trainer.reducer.exposed_samples} steps")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -243,34 +271,72 @@ def main():
             acc[key] = acc.get(key, 0.0) + e0.elapsed_time(e1) / n_ph
         log("main-stream phases, ms/step: " + json.dumps({k: round(v, 2) for k, v in acc.items()}))
 
+    input_edge = None
+    if args.h2d:   # input edge: batches start in pinned host memory, copied one step ahead
+        from jepa_amd.engine.input import DevicePrefetcher
+        hb = make_inputs(dict(wl, distinct_batches=min(4, wl.get("distinct_batches", 4))), 4, rank, device, host=True)
+        cnt = [0]
+
+        def fetch():
+            c, me, mp = hb[cnt[0] % len(hb)]
+            cnt[0] += 1
+            return [c], me, mp
+        pf = DevicePrefetcher(fetch, device)
+        n_h = max(3, min(args.steps, 10))
+
+        def run_h(i):
+            c, me, mp = pf.next()
+            return trainer.train_step(c, me, mp, lr=sched.step(), wd=wd_sched.step(), ema=mom[i % len(mom)])
+        for i in range(2):
+            run_h(i)
+        sync()
+        b0 = pf.bytes_copied
+        t0 = time.perf_counter()
+        for i in range(n_h):
+            run_h(i)
+        sync()
+        dt = time.perf_counter() - t0
+        input_edge = {"ms_per_step": round(1e3 * dt / n_h, 3), "clips_per_s": round(B * n_h / dt, 2),
+                      "h2d_bytes_per_step": int((pf.bytes_copied - b0) / n_h), "resident_ms_per_step":
+                      round(1e3 * elapsed / args.steps, 3),
+                      "note": "pinned host batches -> double-buffered copy stream -> step; never reported as value"}
+        log(f"input-edge run (PCIe-inclusive): {json.dumps(input_edge)}")
+
     roof = None
     if not args.no_roofline_pass:
+        from jepa_amd.engine import chain
         from jepa_amd.engine.layers import side_stream
         side = side_stream(device)
         side.enabled = False       # per-kernel durations are only meaningful when kernels run one at a time
-        ops.KERNEL_TIMERS = {}
+        ops.KERNEL_TIMERS = {}     # launches issued from Python (patch / predictor embed+proj GEMMs and their wgrads)
+        chain.prof_enable(True)    # launches issued by the C chains (every transformer block)
         n_inst = min(3, args.steps)
         for i in range(n_inst):
             run(args.warmup + i)
         sync()
         side.enabled = True
+        chain.prof_enable(False)
         timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
-        fam = {}
+        fam = chain.prof_collect(args.gemm_csv)
         for name, evs in timers.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in evs)
-            fam[name] = dict(launches=len(evs), ms=ms, flop=sum(w for _, _, w in evs))
+            f = fam.setdefault(name, dict(launches=0, ms=0.0, flop=0.0))
+            f["launches"] += len(evs)
+            f["ms"] += sum(s.elapsed_time(e) for s, e, _ in evs)
+            f["flop"] += sum(w for _, _, w in evs)
         g = fam["gemm_nt"]
         ach = g["flop"] / (g["ms"] * 1e-3)
         log(f"roofline pass: {json.dumps({k: dict(v, tflops=round(v['flop'] / v['ms'] / 1e9, 1)) for k, v in fam.items()})}")
         # HBM bytes per launch of the dominant kernel: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
         # correction + WRITE_SIZE), committed under profiles/ -- counters cannot be collected from inside this process
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_hbm_pmc.json")
-        if os.path.exists(pmc) and args.workload == "vitl16":
-            with open(pmc) as fjs:
-                ent = json.load(fjs).get("gemm_nt_8phase_kernel<0>")
-            if ent:
-                traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/r01_d_hbm_pmc.md"
+        for pmc_name in ("r02_hbm_pmc.json", "r01_hbm_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
+            if os.path.exists(pmc) and args.workload == "vitl16":
+                with open(pmc) as fjs:
+                    ent = json.load(fjs).get("gemm_nt_8phase_kernel<0>")
+                if ent:
+                    traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/" + pmc_name
+                    break
         roof = {"bound": "mfma",
                 "kernel": "bf16 MFMA GEMM family (gemm_nt_8phase_kernel 256x256 staggered 8-phase + gemm_nt_kernel "
                           "128x128 split-K wgrads; MFMA 16x16x32, LDS-DMA staged)",
@@ -302,6 +368,8 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if input_edge is not None:
+            line["input_edge"] = input_edge
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -151,12 +151,90 @@ int vj_reg_finish(const float* pstd_sum, int64_t n, int64_t n_masks, float* out,
 int vj_adamw_ema(float* p, const float* g, float* exp_avg, float* exp_avg_sq, void* p_bf16, float* tgt,
                  void* tgt_bf16, int64_t n, float lr, float wd, float beta1, float beta2, float eps, int64_t step,
                  float gscale, float ema, vj_stream_t stream);
+/* Device-guarded form of the same update: nothing between backward and update needs the host.
+ *   gstat = [sumsq_enc, nonfinite_enc, sumsq_pred, nonfinite_pred] (device; two vj_sqnorm_f32 results);
+ *   any non-finite gradient -> AdamW is skipped for every range (GradScaler.step, train.py:471; utils.py:209) while the
+ *   EMA still runs; clip > 0 applies torch.nn.utils.clip_grad_norm_'s coefficient min(1, clip/(norm+1e-6)) with
+ *   norm = sqrt(gstat[2*sel]) * norm_scale (train.py:468-470); the Adam step count t is the device float *step_dev,
+ *   advanced by vj_step_advance only when the step is not skipped. */
+int vj_step_advance(const float* gstat, float* step_dev, vj_stream_t stream);
+int vj_adamw_ema_guarded(float* p, const float* g, float* exp_avg, float* exp_avg_sq, void* p_bf16, float* tgt,
+                         void* tgt_bf16, int64_t n, float lr, float wd, float beta1, float beta2, float eps, float gscale,
+                         float ema, const float* gstat, int sel, float clip, float norm_scale, const float* step_dev,
+                         vj_stream_t stream);
+/* Logging statistics without per-tensor host syncs (grad_logger / adamw_logger, src/utils/logging.py:91-118;
+ * train.py:476-481): desc = device int64 [n_tensors][2] {element offset (multiple of 4), numel} into the flat arenas;
+ * out = device fp32 [n_tensors][vj_grad_stats_chunks()][3] partial sums of {g^2, |exp_avg|, |exp_avg_sq|}
+ * (M1 = M2 = NULL: gradients only).  One launch; evaluated by the caller only when a log line is due. */
+int64_t vj_grad_stats_chunks(void);
+int vj_grad_stats_multi(const float* G, const float* M1, const float* M2, const int64_t* desc, int64_t n_tensors,
+                        float* out, vj_stream_t stream);
 int vj_ema_update(float* tgt, const float* src, void* tgt_bf16, int64_t n, float m, vj_stream_t stream);
 int vj_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, vj_stream_t stream);
 /* out2[0] (+)= sum g^2, out2[1] (+)= count of non-finite values  (clip_grad_norm_, GradScaler inf check) */
 int64_t vj_sqnorm_ws_bytes(void);
 int vj_sqnorm_f32(const float* g, int64_t n, float* out2, int accumulate, void* ws, int64_t ws_bytes,
                   vj_stream_t stream);
+
+/* ---- whole-trunk launch chains (host-side sequencing only; no arithmetic of their own) ------------------------
+ * N transformer blocks, forward or backward, enqueued by ONE call: Block.forward / Attention.forward / MLP.forward
+ * (src/models/utils/modules.py:30-36,61-78,114-120) as the loops of VisionTransformer.forward
+ * (src/models/vision_transformer.py:181-184) and VisionTransformerPredictor.forward (src/models/predictor.py:231-232)
+ * run them, and the autograd graph that loss.backward() (app/vjepa/train.py:461-464) walks over them.
+ * Token rows of several equal-length sequence groups (one per mask) are concatenated along M; `segs` describes them
+ * (attention is launched per segment, everything else over all M rows).
+ * All buffers are borrowed; workspaces are caller-allocated, 256-byte aligned, sized by the *_ws_bytes queries. */
+typedef struct vj_linear {
+  const void* w;    /* bf16 [n_out, k_in]                                   (forward operand)              */
+  const float* b;   /* fp32 [n_out] or NULL                                                                  */
+  const void* wT;   /* bf16 [k_in, ldwT >= n_out] transposed shadow          (dgrad operand; NULL = fwd only) */
+  int64_t ldwT;
+  float* gw;        /* fp32 [n_out, k_in] weight-gradient view               (NULL = fwd only)                */
+  float* gb;        /* fp32 [n_out] bias-gradient view or NULL                                               */
+  int64_t n_out, k_in;
+} vj_linear_t;
+typedef struct vj_norm {
+  const float* g;
+  const float* b;
+  float* gg; /* gradient views, NULL = fwd only */
+  float* gb;
+} vj_norm_t;
+typedef struct vj_block {
+  vj_norm_t norm1;
+  vj_linear_t qkv, proj;
+  vj_norm_t norm2;
+  vj_linear_t fc1, fc2;
+} vj_block_t;
+typedef struct vj_seg {
+  int64_t row0, B, S; /* B sequences of S tokens in rows [row0, row0 + B*S) */
+} vj_seg_t;
+typedef void (*vj_layer_cb_t)(void* user, int layer);
+
+/* save != 0: every block keeps what its backward needs (16*D bf16 per token: x, LN1 out, qkv, o, x1, LN2 out,
+ * pre-GELU u, GELU out + row statistics + softmax lse) in `ws`; save == 0: one such set is reused by all blocks. */
+int64_t vj_blocks_fwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads, int64_t n_blocks, int save);
+/* x_out [M,D] bf16 = blocks[n-1](...blocks[0](x_in)) ; x_in must stay valid until the backward has run. */
+int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M, int64_t D,
+                  int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save, void* ws,
+                  int64_t ws_bytes, vj_stream_t stream);
+int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads);
+/* dx_out [M,D] bf16 = d loss / d x_in given dout = d loss / d x_out; parameter gradients are written as
+ * alpha * grad + beta_acc * old into the fp32 views of `blocks` (beta_acc = 1 accumulates micro-batches).
+ * The dgrad chain runs on `stream`; weight / bias gradients (and the operand transposes feeding them) run on `side`
+ * (NULL = same stream), ordered by events; on return `side` may still hold pending work -- make the consumer of the
+ * gradients wait on it.  on_layer_done(user, l) (nullable) is called from the enqueueing thread as soon as block l's
+ * backward has been enqueued on both streams (gradient-bucket launch hook, DDP equivalent of train.py:295-297).
+ * flags bit0: transpose-free weight gradients (vj_gemm_bf16_tn_splitk). */
+int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, const void* dout, void* dx_out, int64_t M,
+                  int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float alpha, float beta_acc,
+                  const void* save_ws, int64_t save_ws_bytes, void* tmp_ws, int64_t tmp_ws_bytes, int flags,
+                  vj_stream_t stream, vj_stream_t side, vj_layer_cb_t on_layer_done, void* user);
+
+/* ---- per-launch timing of the chains' GEMM / attention launches (HIP events on the launch stream) -------------
+ * vj_prof_enable(1) starts recording; vj_prof_collect synchronises and sums per family (0 GEMM, 1 attention forward,
+ * 2 attention backward): ms[3], flop[3], launches[3]; csv_path (nullable) receives one line per launch. */
+int vj_prof_enable(int on);
+int vj_prof_collect(double* ms, double* flop, int64_t* launches, const char* csv_path);
 
 /* ---- hardware probes (tests / profiles only) ---------------------------------------------------------------- */
 int vj_probe_tr16(uint32_t* out256, int addr_scale, vj_stream_t stream);

@@ -17,12 +17,12 @@ import torch
 import torch.multiprocessing as mp
 
 from ...engine import dp
+from ...engine.input import DevicePrefetcher
 from ...src.datasets.data_manager import init_data
 from ...src.masks.multiblock3d import MaskCollator as MB3DMaskCollator
 from ...src.masks.random_tube import MaskCollator as TubeMaskCollator
 from ...src.utils.distributed import AllReduce, init_distributed
-from ...src.utils.logging import AverageMeter, CSVLogger, get_logger, gpu_timer
-from ...src.utils.tensors import repeat_interleave_batch
+from ...src.utils.logging import AverageMeter, CSVLogger, adamw_logger, get_logger, gpu_timer, grad_logger
 from .utils import init_opt, init_video_model, load_checkpoint
 
 log_timings = True
@@ -103,6 +103,10 @@ def main(args, resume_preempt=False):
     ema = cfgs_opt.get('ema')
     betas = cfgs_opt.get('betas', (0.9, 0.999))
     eps = cfgs_opt.get('eps', 1.e-8)
+    # extension key (absent from the reference schema): clips per micro-batch inside one step.  The 3072-clip ViT-H
+    # recipe puts 384 clips on a GPU; their saved activations do not fit, so the step walks them in micro-batches with
+    # gradient accumulation -- same sums, the collator still draws masks for the whole batch
+    micro_batch = cfgs_opt.get('micro_batch', None)
 
     cfgs_logging = args.get('logging')
     folder = cfgs_logging.get('folder')
@@ -165,7 +169,8 @@ def main(args, resume_preempt=False):
         encoder=encoder, predictor=predictor, target_encoder=target_encoder, wd=wd, final_wd=final_wd,
         start_lr=start_lr, ref_lr=lr, final_lr=final_lr, iterations_per_epoch=ipe, warmup=warmup,
         num_epochs=num_epochs, ipe_scale=ipe_scale, mixed_precision=mixed_precision, betas=betas, eps=eps,
-        loss_exp=loss_exp, reg_coeff=reg_coeff, clip_grad=clip_grad, world_size=world_size, device=device)
+        loss_exp=loss_exp, reg_coeff=reg_coeff, clip_grad=clip_grad, world_size=world_size, device=device,
+        micro_batch=micro_batch)
     trainer = optimizer
     dp.broadcast_parameters(trainer.arena, trainer.tarena)   # DDP's one-time parameter sync (train.py:295-297)
     if world_size > 1:
@@ -176,9 +181,11 @@ def main(args, resume_preempt=False):
 
     start_epoch = 0
     if load_model or os.path.exists(latest_path):
+        # like the reference (train.py:307-320): with meta.load_checkpoint unset, load_path is None, the load fails, is
+        # logged and training starts at epoch 0 -- an existing `-latest` file in a reused folder is NOT auto-resumed
         encoder, predictor, target_encoder, optimizer, scaler, start_epoch = load_checkpoint(
-            r_path=load_path if load_path is not None else latest_path, encoder=encoder, predictor=predictor,
-            target_encoder=target_encoder, opt=optimizer, scaler=scaler)
+            r_path=load_path, encoder=encoder, predictor=predictor, target_encoder=target_encoder, opt=optimizer,
+            scaler=scaler)
         for _ in range(start_epoch * ipe):   # replay schedules and the mask counter (train.py:322-326)
             scheduler.step()
             wd_scheduler.step()
@@ -212,6 +219,21 @@ def main(args, resume_preempt=False):
                 loader = iter(unsupervised_loader)
                 next(loader)
 
+    def fetch_host_batch():
+        """next(loader) with the reference's refresh-on-exhaustion (train.py:372-381); runs one step ahead."""
+        nonlocal loader
+        try:
+            udata, masks_enc, masks_pred = next(loader)
+        except Exception:
+            logger.info('Exhausted data loaders. Refreshing...')
+            loader = iter(unsupervised_loader)
+            udata, masks_enc, masks_pred = next(loader)
+        assert len(masks_enc) == len(masks_pred), 'Currently require num encoder masks = num predictor masks'
+        return udata[0], masks_enc, masks_pred
+
+    # load_clips (train.py:391-408) one batch ahead: pinned staging + copy stream, see engine/input.py
+    prefetcher = DevicePrefetcher(fetch_host_batch, device, batch_size=batch_size, num_clips=num_clips)
+
     for epoch in range(start_epoch, num_epochs):
         logger.info('Epoch %d' % (epoch + 1))
         unsupervised_sampler.set_epoch(epoch)
@@ -222,19 +244,7 @@ def main(args, resume_preempt=False):
 
         for itr in range(ipe):
             itr_start_time = time.time()
-            try:
-                udata, masks_enc, masks_pred = next(loader)
-            except Exception:
-                logger.info('Exhausted data loaders. Refreshing...')
-                loader = iter(unsupervised_loader)
-                udata, masks_enc, masks_pred = next(loader)
-            assert len(masks_enc) == len(masks_pred), 'Currently require num encoder masks = num predictor masks'
-
-            clips = torch.cat([u.to(device, non_blocking=True) for u in udata[0]], dim=0)
-            masks_enc = [repeat_interleave_batch(m.to(device, non_blocking=True), batch_size, repeat=num_clips)
-                         for m in masks_enc]
-            masks_pred = [repeat_interleave_batch(m.to(device, non_blocking=True), batch_size, repeat=num_clips)
-                          for m in masks_pred]
+            clips, masks_enc, masks_pred = prefetcher.next()
             for _i, m in enumerate(mask_meters):
                 m.update(masks_enc[_i][0].size(-1))
 
@@ -244,9 +254,14 @@ def main(args, resume_preempt=False):
                 m = next(momentum_scheduler)
                 out = trainer.train_step(clips, masks_enc, masks_pred, lr=_new_lr, wd=_new_wd, ema=m,
                                          clip_now=(epoch > warmup) and (clip_grad is not None))
-                return (out.loss, out.loss_jepa, out.loss_reg, _new_lr, _new_wd, out.grad_norms)
+                # per-tensor gradient / moment statistics (train.py:476-481) only when their log line is due: one
+                # launch over the arenas instead of ~1000 float() syncs per step
+                stats = None
+                if itr % log_freq == 0:
+                    stats = (grad_logger(trainer, 'enc'), grad_logger(trainer, 'pred'), adamw_logger(trainer))
+                return (out.loss, out.loss_jepa, out.loss_reg, _new_lr, _new_wd, out.grad_norms, stats)
 
-            (loss, loss_jepa, loss_reg, _new_lr, _new_wd, grad_norms), gpu_etime_ms = gpu_timer(train_step)
+            (loss, loss_jepa, loss_reg, _new_lr, _new_wd, grad_norms, stats), gpu_etime_ms = gpu_timer(train_step)
             iter_elapsed_time_ms = (time.time() - itr_start_time) * 1000.
             loss_meter.update(loss)
             if itr % log_freq == 0:   # input statistics only when they are printed (one fused reduction each)
@@ -270,6 +285,18 @@ def main(args, resume_preempt=False):
                                '[' + ', '.join(['%.1f' % m.avg for m in mask_meters]) + ']', _new_wd, _new_lr,
                                torch.cuda.max_memory_allocated() / 1024.0 ** 2, gpu_time_meter.avg,
                                wall_time_meter.avg))
+                if stats is not None:
+                    grad_stats, grad_stats_pred, optim_stats = stats
+                    logger.info('[%d, %5d] first moment: %.2e [%.2e %.2e] second moment: %.2e [%.2e %.2e]'
+                                % (epoch + 1, itr, optim_stats.get('exp_avg').avg, optim_stats.get('exp_avg').min,
+                                   optim_stats.get('exp_avg').max, optim_stats.get('exp_avg_sq').avg,
+                                   optim_stats.get('exp_avg_sq').min, optim_stats.get('exp_avg_sq').max))
+                    logger.info('[%d, %5d] enc_grad_stats: f/l[%.2e %.2e] mn/mx(%.2e, %.2e) %.2e'
+                                % (epoch + 1, itr, grad_stats.first_layer, grad_stats.last_layer, grad_stats.min,
+                                   grad_stats.max, grad_norms[0]))
+                    logger.info('[%d, %5d] pred_grad_stats: f/l[%.2e %.2e] mn/mx(%.2e, %.2e) %.2e'
+                                % (epoch + 1, itr, grad_stats_pred.first_layer, grad_stats_pred.last_layer,
+                                   grad_stats_pred.min, grad_stats_pred.max, grad_norms[1]))
             assert not np.isnan(loss), 'loss is nan'
 
         logger.info('avg. loss %.3f' % loss_meter.avg)

@@ -97,13 +97,14 @@ class _NoScaler:
 def init_opt(encoder, predictor, iterations_per_epoch, start_lr, ref_lr, warmup, num_epochs, wd=1e-6,
              final_wd=1e-6, final_lr=0.0, mixed_precision=False, ipe_scale=1.25, betas=(0.9, 0.999), eps=1e-8,
              zero_init_bias_wd=True, target_encoder=None, loss_exp=1.0, reg_coeff=0.0, clip_grad=None,
-             world_size=1, device=None):
+             world_size=1, device=None, micro_batch=None):
     """Same schedules and parameter grouping as the reference; the returned optimizer is the fused Trainer.
-    Extra keyword arguments (target_encoder, loss_exp, reg_coeff, clip_grad, world_size) configure the step."""
+    Extra keyword arguments (target_encoder, loss_exp, reg_coeff, clip_grad, world_size) configure the step; gradient
+    non-finite checks (GradScaler's skip semantics) are always on and device-side."""
     if target_encoder is None:
         raise ValueError("init_opt needs target_encoder=: the EMA update is fused into the optimizer kernel")
     optimizer = Trainer(encoder, predictor, target_encoder, loss_exp=loss_exp, reg_coeff=reg_coeff, betas=betas,
-                        eps=eps, clip_grad=clip_grad, world_size=world_size, device=device)
+                        eps=eps, clip_grad=clip_grad, world_size=world_size, device=device, micro_batch=micro_batch)
     scheduler = WarmupCosineSchedule(optimizer, warmup_steps=int(warmup * iterations_per_epoch), start_lr=start_lr,
                                      ref_lr=ref_lr, final_lr=final_lr,
                                      T_max=int(ipe_scale * num_epochs * iterations_per_epoch))

@@ -55,10 +55,19 @@ __device__ __forceinline__ void raw_barrier() {   // s_barrier without the vmcnt
 
 #define DEFER_LOG2 5.0f  // forward softmax: rescale O only when a row max grows by more than 2^5
 
+// 16-byte-chunk XOR key of a row.  128/256-byte rows (hd 64/128): row & 7.  64- and 192-byte rows (hd 32 / 96): rows r
+// and r+4 start on the same banks, so the key must separate the four row quads that one ds_read_b128 lane group
+// ({0-3,12-15} of one g with {4-11} of the next) or one ds_read_b64_tr_b16 half (rows 0-7) touches: quads 0,1,2,3 get
+// keys 0,3,2,1 (only the low two chunk bits flip, so a 12-chunk row stays inside itself).  Unswizzled, the hd<=32
+// kernels spent 33-43 % of their LDS cycles in bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
 template <int HDP>
 __device__ __forceinline__ int rm_swz(int row) {
-  return HDP >= 64 ? (row & 7) : 0;
+  if constexpr (HDP % 64 == 0) return row & 7;
+  else return (4 - ((row >> 2) & 3)) & 3;
 }
+// 16-column output tiles of the head dimension: the 96-wide class serves hd <= 80 (ViT-H) with five, not six
+template <int HDP>
+struct HeadTiles { static constexpr int DT = HDP == 96 ? 5 : HDP / 16; };
 
 // ---- row-major image: 64 rows x HDP, 16-byte chunks XOR-swizzled --------------------------------------------
 template <int HDP, int NT = 256>
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
   constexpr int NDMA = RT::CAN_FULL ? RT::NIT : 1;            // DMA instructions per wave per K (or V) tile
   __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * RT::BYTES];
   const TrFrag<HDP> trf(threadIdx.x & 63);
-  constexpr int KS = HDP / 32, DT = HDP / 16;
+  constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
           oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
       }
   };
-  const int nfull = (hd == HDP && RT::CAN_FULL) ? S / 64 : 0;   // complete tiles
+  const int nfull = RT::CAN_FULL ? S / 64 : 0;   // complete 64-key tiles (columns beyond hd are clamped in dma_off)
   const int t_fast = nfull - DIST > 0 ? nfull - DIST : 0;        // iterations t with tiles t and t+DIST complete
   int t = 0;
   for (; t < t_fast; t++) iter(t, std::true_type{});
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
   __shared__ __attribute__((aligned(16))) char smem[2 * BUFB + 2 * 2 * 64 * 4];
   float* stat = (float*)(smem + 2 * BUFB);   // [buffer][lse 0..63 | delta 0..63]
   const TrFrag<HDP> trf(threadIdx.x & 63);
-  constexpr int KS = HDP / 32, DT = HDP / 16;
+  constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   constexpr int NBUF = HDP <= 64 ? 3 : 2, DIST = NBUF - 1, BUFB = 2 * RowTile<HDP>::BYTES, RINGB = NBUF * BUFB;
   __shared__ __attribute__((aligned(16))) char smem[RINGB];
   const TrFrag<HDP> trf(threadIdx.x & 63);
-  constexpr int KS = HDP / 32, DT = HDP / 16;
+  constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -763,7 +772,7 @@ extern "C" int vj_attn_set_variant(int fwd_qt) {
   return 0;
 }
 
-static int pick_hdp(int64_t hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : (hd <= 128 ? 128 : 0)); }
+static int pick_hdp(int64_t hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : (hd <= 80 ? 96 : (hd <= 128 ? 128 : 0))); }
 #define LOG2E 1.4426950408889634f
 
 extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd,
@@ -795,6 +804,7 @@ extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int
       else if (nb_env == 3) VJ_FWD(64, 2, 3);
       else VJ_FWD(64, 2, 2);
       break;
+    case 96: VJ_FWD(96, 2, 2); break;   // hd 65..80 (ViT-H: 80): 3 k-steps, 5 output tiles instead of the 128 class' 4 / 8
     default:
       if (qt_sel == 2) VJ_FWD(128, 2, 2); else VJ_FWD(128, 1, 2);
   }
@@ -833,6 +843,7 @@ extern "C" int vj_attn_bwd(const void* qkv, const void* o, const void* dout, con
   switch (pick_hdp(hd)) {
     case 32: VJ_BWD_LAUNCH(32); break;
     case 64: VJ_BWD_LAUNCH(64); break;
+    case 96: VJ_BWD_LAUNCH(96); break;
     default: VJ_BWD_LAUNCH(128);
   }
 #undef VJ_BWD_LAUNCH

@@ -1,0 +1,403 @@
+// Whole-trunk launch chains: N transformer blocks forward / backward enqueued by ONE C call.
+//
+// Reference semantics (restated, never copied): Block / Attention / MLP forward of src/models/utils/modules.py:30-36,
+// 61-78,114-120 and what autograd derives from them for app/vjepa/train.py:461-464.  The Python engine used to issue the
+// ~1800 kernel launches of a step one ctypes call at a time (~39 us each: 70 ms of host time against an 85 ms GPU step);
+// here the per-block sequence lives behind the C ABI, so the host cost of a block is 7 (forward) / ~25 (backward)
+// hipLaunchKernel calls and nothing else.  No arithmetic happens in this file: it only sequences the kernels of
+// gemm*.hip / attention.hip / norm_loss.hip / rows.hip, lays the saved activations out in a caller-provided workspace
+// and orders the two HIP streams (dgrad chain on `stream`, weight gradients on `side`) with events.
+//
+// Saved-activation layout per block (workspace `save_ws`, everything 256-byte aligned, bf16 unless noted):
+//   x [M,D] (block input; block 0 uses the caller's x_in), y1 [M,D], qkv [M,3D], o [M,D], x1 [M,D], y2 [M,D],
+//   u [M,Dh] (pre-GELU), g [M,Dh], mean1 rstd1 mean2 rstd2 [M] fp32, lse2 [H*M] fp32 (per segment [B,H,S]).
+// With save = 0 (EMA target encoder, inference) one such set is reused by every block and x ping-pongs.
+#include "common.hpp"
+#include "../../include/vjepa_hip.h"
+#include <atomic>
+#include <mutex>
+#include <vector>
+#include <string>
+
+#define CH(call)              \
+  do {                        \
+    int _rc = (call);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+#define HIPCH(call, what)                                                    \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      vj_set_error("%s: %s", what, hipGetErrorString(_e));                   \
+      return (int)_e;                                                        \
+    }                                                                        \
+  } while (0)
+
+static inline int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
+static inline int64_t pad64i(int64_t m) { return (m + 63) / 64 * 64; }
+
+// ---------------------------------------------------------------------------------------------------- event pool
+// Ordering events (no timing) reused round-robin: hipStreamWaitEvent captures the record that precedes it at call time,
+// so an event may be re-recorded as soon as its wait has been enqueued, which always happens inside the same chain call.
+namespace {
+constexpr int POOL = 1024;
+hipEvent_t g_pool[POOL];
+std::once_flag g_pool_once;
+std::atomic<unsigned> g_pool_next{0};
+bool g_pool_ok = false;
+
+hipEvent_t next_event() {
+  std::call_once(g_pool_once, [] {
+    g_pool_ok = true;
+    for (int i = 0; i < POOL; i++)
+      if (hipEventCreateWithFlags(&g_pool[i], hipEventDisableTiming) != hipSuccess) g_pool_ok = false;
+  });
+  return g_pool[g_pool_next.fetch_add(1) % POOL];
+}
+
+// `to` waits for everything enqueued so far on `from`
+int stream_after(hipStream_t to, hipStream_t from, const char* what) {
+  hipEvent_t e = next_event();
+  if (!g_pool_ok) {
+    vj_set_error("%s: could not create ordering events", what);
+    return -2;
+  }
+  HIPCH(hipEventRecord(e, from), what);
+  HIPCH(hipStreamWaitEvent(to, e, 0), what);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- profiler
+// bench.py's roofline object needs per-launch durations of the dominant kernels measured with HIP events on the
+// launch stream.  Off by default (no event is created or recorded); vj_prof_enable(1) starts collecting.
+struct ProfRec {
+  hipEvent_t s, e;
+  int family;   // 0 GEMM, 1 attention forward, 2 attention backward
+  double flop;
+  int64_t m, n, k;
+  int tag;      // epilogue for GEMMs, head_dim for attention
+};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+std::atomic<int> g_prof_on{0};
+
+struct ProfScope {
+  bool on;
+  hipEvent_t s, e;
+  hipStream_t st;
+  int family, tag;
+  double flop;
+  int64_t m, n, k;
+  ProfScope(hipStream_t stream, int fam, double fl, int64_t M, int64_t N, int64_t K, int tg)
+      : on(g_prof_on.load() != 0), st(stream), family(fam), tag(tg), flop(fl), m(M), n(N), k(K) {
+    if (!on) return;
+    if (hipEventCreate(&s) != hipSuccess || hipEventCreate(&e) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(s, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({s, e, family, flop, m, n, k, tag});
+  }
+};
+}  // namespace
+
+extern "C" int vj_prof_enable(int on) {
+  g_prof_on.store(on ? 1 : 0);
+  return 0;
+}
+
+// Sums per family: ms[3], flop[3], launches[3]; optional CSV of every launch (family,tag,m,n,k,us) at csv_path.
+// Synchronises the recorded events (call after the work has been enqueued); clears the records.
+extern "C" int vj_prof_collect(double* ms, double* flop, int64_t* launches, const char* csv_path) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int i = 0; i < 3; i++) {
+    ms[i] = 0.0;
+    flop[i] = 0.0;
+    launches[i] = 0;
+  }
+  FILE* f = csv_path && csv_path[0] ? fopen(csv_path, "w") : nullptr;
+  if (f) fprintf(f, "family,tag,m,n,k,us\n");
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    HIPCH(hipEventSynchronize(r.e), "vj_prof_collect");
+    HIPCH(hipEventElapsedTime(&t, r.s, r.e), "vj_prof_collect");
+    ms[r.family] += t;
+    flop[r.family] += r.flop;
+    launches[r.family] += 1;
+    if (f) fprintf(f, "%d,%d,%ld,%ld,%ld,%.3f\n", r.family, r.tag, (long)r.m, (long)r.n, (long)r.k, 1e3 * t);
+    (void)hipEventDestroy(r.s);
+    (void)hipEventDestroy(r.e);
+  }
+  if (f) fclose(f);
+  g_prof.clear();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- launch helpers
+static int gemm(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                int64_t K, const float* bias, const void* res, int64_t ldr, const void* aux_in, void* aux_out,
+                int64_t ldaux, int epi, hipStream_t st) {
+  ProfScope ps(st, 0, 2.0 * M * N * K, M, N, K, epi);
+  return vj_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, res, ldr, aux_in, aux_out, ldaux, epi, 1.0f, 0.0f, 0, st);
+}
+
+struct FwdLayout {
+  int64_t x, y1, qkv, o, x1, y2, u, g, mean1, rstd1, mean2, rstd2, lse, total;
+};
+static FwdLayout fwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
+  FwdLayout L;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    int64_t o = off;
+    off += al256(bytes);
+    return o;
+  };
+  L.x = take(M * D * 2);
+  L.y1 = take(M * D * 2);
+  L.qkv = take(M * 3 * D * 2);
+  L.o = take(M * D * 2);
+  L.x1 = take(M * D * 2);
+  L.y2 = take(M * D * 2);
+  L.u = take(M * Dh * 2);
+  L.g = take(M * Dh * 2);
+  L.mean1 = take(M * 4);
+  L.rstd1 = take(M * 4);
+  L.mean2 = take(M * 4);
+  L.rstd2 = take(M * 4);
+  L.lse = take(H * M * 4);
+  L.total = off;
+  return L;
+}
+
+extern "C" int64_t vj_blocks_fwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads, int64_t n_blocks, int save) {
+  const FwdLayout L = fwd_layout(M, D, Dh, heads);
+  return save ? L.total * n_blocks : L.total + al256(M * D * 2);
+}
+
+static int check_blocks(const vj_block_t* blocks, int64_t n_blocks, int64_t D, const char* who) {
+  VJ_CHECK_ARG(blocks != nullptr && n_blocks > 0, "%s: no blocks", who);
+  const int64_t Dh = blocks[0].fc1.n_out;
+  for (int64_t i = 0; i < n_blocks; i++) {
+    const vj_block_t& b = blocks[i];
+    VJ_CHECK_ARG(b.qkv.n_out == 3 * D && b.qkv.k_in == D && b.proj.n_out == D && b.proj.k_in == D && b.fc1.n_out == Dh &&
+                     b.fc1.k_in == D && b.fc2.n_out == D && b.fc2.k_in == Dh,
+                 "%s: block %ld has inconsistent Linear shapes for D=%ld", who, (long)i, (long)D);
+  }
+  return 0;
+}
+
+static int check_segs(const vj_seg_t* segs, int64_t n_segs, int64_t M, const char* who) {
+  VJ_CHECK_ARG(segs != nullptr && n_segs > 0, "%s: no segments", who);
+  int64_t r = 0;
+  for (int64_t i = 0; i < n_segs; i++) {
+    VJ_CHECK_ARG(segs[i].row0 == r && segs[i].B >= 0 && segs[i].S >= 0, "%s: segments must tile the rows in order", who);
+    r += segs[i].B * segs[i].S;
+  }
+  VJ_CHECK_ARG(r == M, "%s: segments cover %ld rows, M=%ld", who, (long)r, (long)M);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M,
+                             int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save,
+                             void* ws, int64_t ws_bytes, hipStream_t stream) {
+  CH(check_blocks(blocks, n_blocks, D, "vj_blocks_fwd"));
+  CH(check_segs(segs, n_segs, M, "vj_blocks_fwd"));
+  VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_fwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
+  if (M == 0) return 0;
+  const int64_t Dh = blocks[0].fc1.n_out, hd = D / heads;
+  const float scale = 1.0f / sqrtf((float)hd);
+  VJ_CHECK_ARG(ws != nullptr && ws_bytes >= vj_blocks_fwd_ws_bytes(M, D, Dh, heads, n_blocks, save),
+               "vj_blocks_fwd: workspace too small (%ld < %ld)", (long)ws_bytes,
+               (long)vj_blocks_fwd_ws_bytes(M, D, Dh, heads, n_blocks, save));
+  VJ_CHECK_ARG(((uintptr_t)ws & 255) == 0, "vj_blocks_fwd: workspace must be 256-byte aligned");
+  const FwdLayout L = fwd_layout(M, D, Dh, heads);
+  char* base = (char*)ws;
+  char* pingpong[2] = {base + L.x, base + L.total};   // save = 0: block outputs alternate between these two
+  const char* x = (const char*)x_in;
+  for (int64_t li = 0; li < n_blocks; li++) {
+    const vj_block_t& b = blocks[li];
+    char* w = save ? base + li * L.total : base;
+    char* x2;
+    if (li == n_blocks - 1) x2 = (char*)x_out;
+    else if (save) x2 = base + (li + 1) * L.total + L.x;
+    else x2 = pingpong[li & 1];
+    float* mean1 = save ? (float*)(w + L.mean1) : nullptr;
+    float* rstd1 = save ? (float*)(w + L.rstd1) : nullptr;
+    float* mean2 = save ? (float*)(w + L.mean2) : nullptr;
+    float* rstd2 = save ? (float*)(w + L.rstd2) : nullptr;
+    CH(vj_layernorm_fwd(x, b.norm1.g, b.norm1.b, w + L.y1, mean1, rstd1, M, D, ln_eps, stream));
+    CH(gemm(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 0, stream));
+    for (int64_t s = 0; s < n_segs; s++) {
+      const vj_seg_t& sg = segs[s];
+      if (sg.B * sg.S == 0) continue;
+      float* lse = save ? (float*)(w + L.lse) + heads * sg.row0 : nullptr;
+      ProfScope ps(stream, 1, 4.0 * sg.B * heads * sg.S * sg.S * hd, sg.B, sg.S, heads, (int)hd);
+      CH(vj_attn_fwd(w + L.qkv + sg.row0 * 3 * D * 2, w + L.o + sg.row0 * D * 2, lse, sg.B, sg.S, heads, hd, scale,
+                     stream));
+    }
+    CH(gemm(w + L.o, D, b.proj.w, D, w + L.x1, D, M, D, D, b.proj.b, x, D, nullptr, nullptr, 0, 0, stream));
+    CH(vj_layernorm_fwd(w + L.x1, b.norm2.g, b.norm2.b, w + L.y2, mean2, rstd2, M, D, ln_eps, stream));
+    CH(gemm(w + L.y2, D, b.fc1.w, D, w + L.g, Dh, M, Dh, D, b.fc1.b, nullptr, 0, nullptr, save ? w + L.u : nullptr, Dh,
+            1, stream));
+    CH(gemm(w + L.g, Dh, b.fc2.w, Dh, x2, D, M, D, Dh, b.fc2.b, w + L.x1, D, nullptr, nullptr, 0, 0, stream));
+    x = x2;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- backward
+#define WGRAD_WS_BYTES ((int64_t)96 << 20)
+
+struct BwdLayout {
+  int64_t du[2], dx1[2], dqkv[2], dx[3], dy2, dob, dy1, delta, ln_ws, dyT, xT, tcs_ws, wg_ws, total;
+  int64_t ln_ws_bytes, tcs_ws_bytes, delta_bytes;
+};
+static BwdLayout bwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
+  BwdLayout L;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    int64_t o = off;
+    off += al256(bytes);
+    return o;
+  };
+  const int64_t Mp = pad64i(M), nmax = 3 * D > Dh ? 3 * D : Dh;
+  for (int p = 0; p < 2; p++) {
+    L.du[p] = take(M * Dh * 2);
+    L.dx1[p] = take(M * D * 2);
+    L.dqkv[p] = take(M * 3 * D * 2);
+  }
+  for (int p = 0; p < 3; p++) L.dx[p] = take(M * D * 2);
+  L.dy2 = take(M * D * 2);
+  L.dob = take(M * D * 2);
+  L.dy1 = take(M * D * 2);
+  L.delta_bytes = H * M * 4;
+  L.delta = take(L.delta_bytes);
+  L.ln_ws_bytes = vj_layernorm_bwd_ws_bytes(D);
+  L.ln_ws = take(L.ln_ws_bytes);
+  L.dyT = take(nmax * Mp * 2);
+  L.xT = take(Dh * Mp * 2);
+  L.tcs_ws_bytes = vj_transpose_colsum_ws_bytes(M, nmax);
+  if (vj_colsum_ws_bytes(nmax) > L.tcs_ws_bytes) L.tcs_ws_bytes = vj_colsum_ws_bytes(nmax);
+  L.tcs_ws = take(L.tcs_ws_bytes);
+  L.wg_ws = take(WGRAD_WS_BYTES);
+  L.total = off;
+  return L;
+}
+
+extern "C" int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads) {
+  return bwd_layout(M, D, Dh, heads).total;
+}
+
+struct SideCtx {
+  hipStream_t main, side;   // side == main: serial mode
+  char* tmp;
+  const BwdLayout* L;
+  int64_t M;
+  float alpha, beta;
+  int tn;
+};
+
+// dW (fp32, += beta*old) = alpha * dy^T x_in ; db = alpha * colsum(dy) -- on the side stream, after `main` produced dy
+static int wgrad(const SideCtx& c, const void* dy, const void* x_in, const vj_linear_t& lw) {
+  const int64_t M = c.M, Mp = pad64i(M), N = lw.n_out, K = lw.k_in;
+  if (c.side != c.main) CH(stream_after(c.side, c.main, "vj_blocks_bwd(fork)"));
+  hipStream_t st = c.side;
+  if (c.tn && N % 8 == 0 && K % 8 == 0) {
+    if (lw.gb) CH(vj_colsum_bf16(dy, M, N, N, M > 0 ? M : 1, 0, M > 0 ? M : 1, lw.gb, c.alpha, c.beta, c.tmp + c.L->tcs_ws,
+                                 c.L->tcs_ws_bytes, st));
+    ProfScope ps(st, 0, 2.0 * M * N * K, N, K, M, 3);
+    return vj_gemm_bf16_tn_splitk(dy, N, x_in, K, lw.gw, K, M, N, K, c.alpha, c.beta, c.tmp + c.L->wg_ws, WGRAD_WS_BYTES, st);
+  }
+  char* dyT = c.tmp + c.L->dyT;
+  char* xT = c.tmp + c.L->xT;
+  if (lw.gb) CH(vj_transpose_colsum_bf16(dy, dyT, M, N, N, Mp, lw.gb, c.alpha, c.beta, c.tmp + c.L->tcs_ws,
+                                         c.L->tcs_ws_bytes, st));
+  else CH(vj_transpose_bf16(dy, dyT, M, N, N, Mp, st));
+  CH(vj_transpose_bf16(x_in, xT, M, K, K, Mp, st));
+  ProfScope ps(st, 0, 2.0 * N * K * Mp, N, K, Mp, 3);
+  return vj_gemm_bf16_nt_splitk(dyT, Mp, xT, Mp, lw.gw, K, N, K, Mp, c.alpha, c.beta, 0, c.tmp + c.L->wg_ws,
+                                WGRAD_WS_BYTES, st);
+}
+
+extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, const void* dout, void* dx_out,
+                             int64_t M, int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float alpha,
+                             float beta_acc, const void* save_ws, int64_t save_ws_bytes, void* tmp_ws,
+                             int64_t tmp_ws_bytes, int flags, hipStream_t stream, hipStream_t side,
+                             vj_layer_cb_t on_layer_done, void* user) {
+  CH(check_blocks(blocks, n_blocks, D, "vj_blocks_bwd"));
+  CH(check_segs(segs, n_segs, M, "vj_blocks_bwd"));
+  VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_bwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
+  if (M == 0) return 0;
+  const int64_t Dh = blocks[0].fc1.n_out, hd = D / heads;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const FwdLayout F = fwd_layout(M, D, Dh, heads);
+  const BwdLayout L = bwd_layout(M, D, Dh, heads);
+  VJ_CHECK_ARG(save_ws != nullptr && save_ws_bytes >= F.total * n_blocks, "vj_blocks_bwd: saved-activation workspace too small");
+  VJ_CHECK_ARG(tmp_ws != nullptr && tmp_ws_bytes >= L.total, "vj_blocks_bwd: temporary workspace too small (%ld < %ld)",
+               (long)tmp_ws_bytes, (long)L.total);
+  VJ_CHECK_ARG((((uintptr_t)save_ws | (uintptr_t)tmp_ws) & 255) == 0, "vj_blocks_bwd: workspaces must be 256-byte aligned");
+  for (int64_t i = 0; i < n_blocks; i++) {
+    const vj_block_t& b = blocks[i];
+    VJ_CHECK_ARG(b.qkv.wT && b.proj.wT && b.fc1.wT && b.fc2.wT && b.qkv.gw && b.proj.gw && b.fc1.gw && b.fc2.gw &&
+                     b.norm1.gg && b.norm1.gb && b.norm2.gg && b.norm2.gb,
+                 "vj_blocks_bwd: block %ld lacks transposed weights / gradient views", (long)i);
+  }
+  const char* sv = (const char*)save_ws;
+  char* tmp = (char*)tmp_ws;
+  SideCtx sc{stream, side ? side : stream, tmp, &L, M, alpha, beta_acc, flags & 1};
+  constexpr int MAX_BLOCKS = 256;
+  VJ_CHECK_ARG(n_blocks <= MAX_BLOCKS, "vj_blocks_bwd: more than %d blocks", MAX_BLOCKS);
+  hipEvent_t side_done[MAX_BLOCKS];
+  const char* dx2 = (const char*)dout;
+  for (int64_t li = n_blocks - 1; li >= 0; li--) {
+    const vj_block_t& b = blocks[li];
+    const char* w = sv + li * F.total;
+    const char* x = li == 0 ? (const char*)x_in : w + F.x;
+    const int p = (int)(li & 1);
+    char* du = tmp + L.du[p];
+    char* dx1 = tmp + L.dx1[p];
+    char* dqkv = tmp + L.dqkv[p];
+    char* dx = li == 0 ? (char*)dx_out : tmp + L.dx[li % 3];
+    // the buffers this block is about to overwrite were last read by the weight gradients of block li+2
+    if (sc.side != sc.main && li + 2 < n_blocks) HIPCH(hipStreamWaitEvent(stream, side_done[li + 2], 0), "vj_blocks_bwd");
+    // fc2: dgrad fused with GELU' ; wgrad reads (dx2, g)
+    CH(wgrad(sc, dx2, w + F.g, b.fc2));
+    CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream));
+    // fc1
+    CH(wgrad(sc, du, w + F.y2, b.fc1));
+    CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream));
+    CH(vj_layernorm_bwd(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
+                        dx1, b.norm2.gg, b.norm2.gb, alpha, beta_acc, M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    // proj
+    CH(wgrad(sc, dx1, w + F.o, b.proj));
+    CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream));
+    for (int64_t s = 0; s < n_segs; s++) {
+      const vj_seg_t& sg = segs[s];
+      if (sg.B * sg.S == 0) continue;
+      ProfScope ps(stream, 2, 8.0 * sg.B * heads * sg.S * sg.S * hd, sg.B, sg.S, heads, (int)hd);
+      CH(vj_attn_bwd(w + F.qkv + sg.row0 * 3 * D * 2, w + F.o + sg.row0 * D * 2, tmp + L.dob + sg.row0 * D * 2,
+                     (const float*)(w + F.lse) + heads * sg.row0, dqkv + sg.row0 * 3 * D * 2, sg.B, sg.S, heads, hd, scale,
+                     tmp + L.delta, L.delta_bytes, stream));
+    }
+    // qkv
+    CH(wgrad(sc, dqkv, w + F.y1, b.qkv));
+    CH(gemm(dqkv, 3 * D, b.qkv.wT, b.qkv.ldwT, tmp + L.dy1, D, M, D, 3 * D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0,
+            stream));
+    CH(vj_layernorm_bwd(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
+                        b.norm1.gg, b.norm1.gb, alpha, beta_acc, M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    if (sc.side != sc.main) {
+      hipEvent_t e = next_event();
+      HIPCH(hipEventRecord(e, sc.side), "vj_blocks_bwd");
+      side_done[li] = e;
+    }
+    if (on_layer_done) on_layer_done(user, (int)li);
+    dx2 = dx;
+  }
+  return 0;
+}

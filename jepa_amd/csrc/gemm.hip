@@ -218,12 +218,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
 template <int BK, int NS, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
   constexpr int smem = NS * (BM + BN) * BK * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // function-local static with an initialiser: set exactly once, thread-safe (the C ABI is re-entrant)
+  static const bool attr_set = [] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, NS, EPI, GLDS, BM, BN, WM, WN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   GemmArgs b = a;
   b.tiles_m = (int)cdiv64(a.M, BM);
   b.tiles_n = (int)cdiv64(a.N, BN);

@@ -236,11 +236,12 @@ __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, in
 template <int EPI>
 static int launch8(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
   constexpr int smem = 8 * PART_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // function-local static with an initialiser: set exactly once, thread-safe (the C ABI is re-entrant)
+  static const bool attr_set = [] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_8phase_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   GemmArgs b = a;
   b.tiles_m = (int)cdiv64(a.M, P8_BM);
   b.tiles_n = (int)cdiv64(a.N, P8_BN);

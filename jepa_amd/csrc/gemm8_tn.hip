@@ -285,11 +285,12 @@ extern "C" int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X
     }
   }
   constexpr int smem = 8 * TN_PART_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // function-local static with an initialiser: set exactly once, thread-safe (the C ABI is re-entrant)
+  static const bool attr_set = [] {
     (void)hipFuncSetAttribute((const void*)gemm_tn_8phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    return true;
+  }();
+  (void)attr_set;
   GemmArgs b;
   b.A = (const bf16_t*)dY; b.B = (const bf16_t*)X; b.C = dW; b.bias = nullptr; b.res = nullptr; b.aux_in = nullptr;
   b.aux_out = nullptr;

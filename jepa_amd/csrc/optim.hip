@@ -18,10 +18,50 @@ struct AdamArgs {
   float bc1, bc2_sqrt;  // 1-beta1^t, sqrt(1-beta2^t)
   float gscale;         // gradient pre-scale (clip coefficient / all-reduce mean)
   float ema;            // momentum m
+  // device-side guard (vj_adamw_ema_guarded; all nullable / 0 for the plain entry point):
+  const float* gstat;   // [sumsq_0, nonfinite_0, sumsq_1, nonfinite_1] of the (summed) gradients, from vj_sqnorm_f32
+  int sel;              // which sumsq belongs to this parameter range (clip_grad_norm_ is per module, train.py:469-470)
+  float clip;           // max norm (<= 0: no clipping)
+  float norm_scale;     // gradient norm = sqrt(sumsq) * norm_scale (1/world for summed data-parallel gradients)
+  const float* step_dev;  // device step counter t (already advanced by vj_step_advance); bias corrections from it
 };
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   const int64_t n4 = a.n >> 2;
+  bool skip = false;
+  if (a.gstat) {
+    // GradScaler semantics (scaler.step, train.py:471): any non-finite gradient anywhere -> no optimizer step at all;
+    // the EMA of train.py:483-487 still runs (against the unchanged weights).  Decided on the device: no host sync.
+    skip = (a.gstat[1] + a.gstat[3]) > 0.f;
+    if (a.clip > 0.f) {   // torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6))
+      const float norm = sqrtf(a.gstat[2 * a.sel]) * a.norm_scale;
+      a.gscale *= fminf(1.0f, a.clip / (norm + 1e-6f));
+    }
+  }
+  if (a.step_dev) {
+    const double t = (double)*a.step_dev;
+    a.bc1 = (float)(1.0 - pow((double)a.beta1, t));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
+  }
+  if (skip) {
+    if (!a.tgt) return;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+      const float4 p = ((const float4*)a.p)[q];
+      float4 t = ((float4*)a.tgt)[q];
+      t.x = t.x * a.ema + (1.0f - a.ema) * p.x;
+      t.y = t.y * a.ema + (1.0f - a.ema) * p.y;
+      t.z = t.z * a.ema + (1.0f - a.ema) * p.z;
+      t.w = t.w * a.ema + (1.0f - a.ema) * p.w;
+      ((float4*)a.tgt)[q] = t;
+      if (a.tgt_bf16) {
+        u32x2_t w;
+        w[0] = pack_bf2(t.x, t.y);
+        w[1] = pack_bf2(t.z, t.w);
+        ((u32x2_t*)a.tgt_bf16)[q] = w;
+      }
+    }
+    return;
+  }
   const float step = a.lr / a.bc1;
   const float decay = 1.0f - a.lr * a.wd;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
@@ -85,8 +125,38 @@ extern "C" int vj_adamw_ema(float* p, const float* g, float* exp_avg, float* exp
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   a.gscale = gscale; a.ema = ema;
+  a.gstat = nullptr; a.sel = 0; a.clip = 0.f; a.norm_scale = 1.f; a.step_dev = nullptr;
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, a);
   VJ_LAUNCH_CHECK("vj_adamw_ema");
+  return 0;
+}
+
+// Device-guarded form: skip-on-non-finite, clip coefficient and the Adam step count are all read from device memory,
+// so the host never synchronises between backward and update (the reference pays a float() in clip_grad_norm_ and
+// an inf-check sync inside GradScaler.step, train.py:465-472).
+__global__ void step_advance_kernel(const float* __restrict__ gstat, float* __restrict__ step_dev) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !((gstat[1] + gstat[3]) > 0.f)) *step_dev += 1.0f;
+}
+extern "C" int vj_step_advance(const float* gstat, float* step_dev, hipStream_t stream) {
+  VJ_CHECK_ARG(gstat != nullptr && step_dev != nullptr, "vj_step_advance: null pointer");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, stream, gstat, step_dev);
+  VJ_LAUNCH_CHECK("vj_step_advance");
+  return 0;
+}
+extern "C" int vj_adamw_ema_guarded(float* p, const float* g, float* exp_avg, float* exp_avg_sq, void* p_bf16, float* tgt,
+                                    void* tgt_bf16, int64_t n, float lr, float wd, float beta1, float beta2, float eps,
+                                    float gscale, float ema, const float* gstat, int sel, float clip, float norm_scale,
+                                    const float* step_dev, hipStream_t stream) {
+  VJ_CHECK_ARG(n % 4 == 0, "vj_adamw_ema_guarded: segment length %ld must be a multiple of 4 (pad the arena)", (long)n);
+  VJ_CHECK_ARG(gstat != nullptr && step_dev != nullptr && (sel == 0 || sel == 1), "vj_adamw_ema_guarded: bad guard arguments");
+  if (n == 0) return 0;
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = exp_avg; a.v = exp_avg_sq; a.p_bf16 = (bf16_t*)p_bf16; a.tgt = tgt;
+  a.tgt_bf16 = (bf16_t*)tgt_bf16; a.n = n; a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = 1.f; a.bc2_sqrt = 1.f; a.gscale = gscale; a.ema = ema;
+  a.gstat = gstat; a.sel = sel; a.clip = clip; a.norm_scale = norm_scale; a.step_dev = step_dev;
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, a);
+  VJ_LAUNCH_CHECK("vj_adamw_ema_guarded");
   return 0;
 }
 
@@ -191,5 +261,65 @@ extern "C" int vj_sqnorm_f32(const float* g, int64_t n, float* out2, int accumul
   VJ_LAUNCH_CHECK("vj_sqnorm_f32");
   hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, out2, accumulate);
   VJ_LAUNCH_CHECK("vj_sqnorm_f32(finish)");
+  return 0;
+}
+
+// Per-tensor statistics of the gradient / Adam-moment arenas in ONE launch (reference: grad_logger + adamw_logger,
+// src/utils/logging.py:91-118, which cost one float() host sync per tensor, ~1000 per step).  desc[t] = {offset, numel}
+// (elements, offset % 4 == 0 -- arena slots are 64-aligned); out[t][c][0..2] = partial sums over chunk c of
+// {g^2, |exp_avg|, |exp_avg_sq|}; the caller adds the GS_CHUNKS partials (a 30 KB copy, only when a log line is due).
+#define GS_CHUNKS 8
+__global__ __launch_bounds__(256) void grad_stats_multi_kernel(const float* __restrict__ G, const float* __restrict__ M1,
+                                                               const float* __restrict__ M2,
+                                                               const int64_t* __restrict__ desc, float* __restrict__ out) {
+  __shared__ float red[3][4];
+  const int t = blockIdx.x, c = blockIdx.y;
+  const int64_t off = desc[2 * t], n = desc[2 * t + 1];
+  const int64_t per = cdiv64(cdiv64(n, GS_CHUNKS), 4) * 4;   // chunk length, multiple of 4
+  const int64_t lo = (int64_t)c * per, hi = lo + per < n ? lo + per : n;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  const int64_t n4 = hi > lo ? (hi - lo) >> 2 : 0;
+  for (int64_t q = threadIdx.x; q < n4; q += 256) {
+    const int64_t e = off + lo + 4 * q;
+    const float4 g = *(const float4*)(G + e);
+    s0 += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+    if (M1) {
+      const float4 a = *(const float4*)(M1 + e);
+      const float4 b = *(const float4*)(M2 + e);
+      s1 += fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w);
+      s2 += fabsf(b.x) + fabsf(b.y) + fabsf(b.z) + fabsf(b.w);
+    }
+  }
+  for (int64_t e = lo + 4 * n4 + threadIdx.x; e < hi; e += 256) {   // tail (numel % 4 != 0 only in the last chunk)
+    const float g = G[off + e];
+    s0 += g * g;
+    if (M1) {
+      s1 += fabsf(M1[off + e]);
+      s2 += fabsf(M2[off + e]);
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s0;
+    red[1][threadIdx.x >> 6] = s1;
+    red[2][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    out[((int64_t)t * GS_CHUNKS + c) * 3 + threadIdx.x] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+extern "C" int64_t vj_grad_stats_chunks(void) { return GS_CHUNKS; }
+extern "C" int vj_grad_stats_multi(const float* G, const float* M1, const float* M2, const int64_t* desc, int64_t n_tensors,
+                                   float* out, hipStream_t stream) {
+  VJ_CHECK_ARG(G != nullptr && desc != nullptr && out != nullptr, "vj_grad_stats_multi: null pointer");
+  VJ_CHECK_ARG((M1 == nullptr) == (M2 == nullptr), "vj_grad_stats_multi: pass both moment arenas or neither");
+  VJ_CHECK_ARG(n_tensors >= 0 && n_tensors < 65536, "vj_grad_stats_multi: bad tensor count");
+  if (n_tensors == 0) return 0;
+  hipLaunchKernelGGL(grad_stats_multi_kernel, dim3((unsigned)n_tensors, GS_CHUNKS), dim3(256), 0, stream, G, M1, M2, desc,
+                     out);
+  VJ_LAUNCH_CHECK("vj_grad_stats_multi");
   return 0;
 }

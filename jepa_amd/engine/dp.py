@@ -30,6 +30,8 @@ class GradReducer:
         self._pending = []
         self.comm_stream = None
         self.launched = []     # (lo, hi) in launch order -- inspected by tests
+        self._exposed = []     # (event before, event after) the compute stream's wait on the collectives, per step
+        self.exposed_samples = 0
         if not self.enabled:
             return
         sl = arena.slots
@@ -96,10 +98,23 @@ class GradReducer:
         for lo, hi in self.tail:
             self._reduce(lo, hi)
         if self.arena.G.is_cuda and self.overlap:
+            cur = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
             for w in self._pending:
                 w.wait()   # enqueues a wait of the current (compute) stream on the collective; no host block
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cur.wait_stream(self.comm_stream)
+            e1.record(cur)   # e0 -> e1 on the compute stream = communication NOT hidden under the backward
+            self._exposed = (self._exposed + [(e0, e1)])[-16:]
         self._pending = []
+
+    def exposed_ms(self):
+        """Mean time per step the compute stream sat waiting for the gradient collectives (synchronises)."""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize()
+        self.exposed_samples = len(self._exposed)
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
 
 
 def broadcast_parameters(arena, tarena=None, src=0):

@@ -81,7 +81,14 @@ class _ModuleFn(torch.autograd.Function):
             in_grads = bwd_fn(module, views, saved, dout.contiguous())
         in_grads = list(in_grads) if in_grads is not None else []
         in_grads += [None] * (n_diff - len(in_grads))
-        pgrads = [arena.grad(prefix + n).clone() for n in names]
+        # Parameters attached to a Trainer already have .grad aliasing the arena slot the chain just wrote: returning a
+        # tensor for them would make autograd ADD it onto the same memory (doubling the gradient); return None there.
+        pgrads = []
+        for n in names:
+            g = arena.grad(prefix + n)
+            p = arena.slots[prefix + n].param
+            aliased = p.grad is not None and p.grad.data_ptr() == g.data_ptr()
+            pgrads.append(None if aliased else g.clone())
         return (None, None, None, None, None, *in_grads, *pgrads)
 
 

@@ -19,6 +19,7 @@ from typing import List, Optional
 import torch
 
 from ..hip import ops
+from . import chain
 from .weights import BlockW, EncoderW, LinearW, PredictorW
 
 LN_EPS = 1e-6  # partial(nn.LayerNorm, eps=1e-6), vision_transformer.py:252-281 / predictor.py:242-246
@@ -49,10 +50,19 @@ _SIDE = {}
 
 
 def side_stream(device):
-    s = _SIDE.get(device)
+    """One SideStream per GPU, keyed by device INDEX: torch.device('cuda') and torch.device('cuda:0') are different
+    dictionary keys but the same GPU, and the fork/join partners must be the same stream object."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _SIDE.get(idx)
     if s is None:
-        s = _SIDE[device] = SideStream(device)
+        s = _SIDE[idx] = SideStream(torch.device("cuda", idx))
     return s
+
+
+# The C launch chains (vj_blocks_fwd / vj_blocks_bwd) are the default for the Trainer; VJ_PY_CHAIN=1 keeps the
+# per-kernel Python chain below (same kernels, same order: bit-identical results, ~10x the host time).
+USE_C_CHAIN = os.environ.get("VJ_PY_CHAIN", "0") != "1"
 
 
 @dataclass
@@ -107,27 +117,28 @@ def _tn_ok(n_out: int, k_in: int) -> bool:
     return WGRAD_TN and n_out % 8 == 0 and k_in % 8 == 0 and waste(n_out) * waste(k_in) <= 1.10
 
 
-def _wgrad(dy, x_in, lw: LinearW, alpha: float):
+def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0):
+    acc = beta != 0.0
     if _tn_ok(dy.shape[1], x_in.shape[1]):
         if lw.gb is not None:
-            ops.colsum(dy, lw.gb, alpha=alpha)
-        ops.gemm_wgrad_tn(dy, x_in, lw.gw, alpha=alpha)
+            ops.colsum(dy, lw.gb, alpha=alpha, accumulate=acc)
+        ops.gemm_wgrad_tn(dy, x_in, lw.gw, alpha=alpha, beta=beta)
         return
-    dyT = ops.transpose_colsum(dy, lw.gb, alpha=alpha) if lw.gb is not None else ops.transpose(dy)
+    dyT = ops.transpose_colsum(dy, lw.gb, alpha=alpha, accumulate=acc) if lw.gb is not None else ops.transpose(dy)
     xT = ops.transpose(x_in)
-    ops.gemm_wgrad(dyT, xT, lw.gw, alpha=alpha)
+    ops.gemm_wgrad(dyT, xT, lw.gw, alpha=alpha, beta=beta)
 
 
-def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None):
-    """dW (fp32, into lw.gw) = alpha * dy^T x_in ; db = alpha * colsum(dy) ; returns dx = dy W (bf16).
+def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None, beta: float = 0.0):
+    """dW (fp32, into lw.gw) = alpha * dy^T x_in + beta * dW ; db likewise ; returns dx = dy W (bf16).
     The weight-gradient half goes to the side stream; the caller joins before the gradients are consumed."""
     side = side_stream(dy.device)
     if side.enabled:
         side.fork(dy, x_in)
         with torch.cuda.stream(side.stream):
-            _wgrad(dy, x_in, lw, alpha)
+            _wgrad(dy, x_in, lw, alpha, beta)
     else:
-        _wgrad(dy, x_in, lw, alpha)
+        _wgrad(dy, x_in, lw, alpha, beta)
     if not need_dx:
         return None
     if dgelu_aux is not None:
@@ -135,25 +146,28 @@ def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_au
     return ops.gemm_nt(dy, lw.wT)
 
 
-def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: float):
+def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: float, beta: float = 0.0):
     x, y1, mean1, rstd1, qkv, o, lses, x1, y2, mean2, rstd2, u, g = saved
     D = x.shape[1]
     hd = D // heads
     scale = hd ** -0.5
-    du = _linear_backward(dx2, g, bw.fc2, alpha, dgelu_aux=u)           # fc2 dgrad fused with GELU'
-    dy2 = _linear_backward(du, y2, bw.fc1, alpha)
-    dx1 = ops.layernorm_bwd(dy2, x1, bw.norm2.g, mean2, rstd2, bw.norm2.gg, bw.norm2.gb, dres=dx2, alpha=alpha)
-    do = _linear_backward(dx1, o, bw.proj, alpha)
+    acc = beta != 0.0
+    du = _linear_backward(dx2, g, bw.fc2, alpha, dgelu_aux=u, beta=beta)   # fc2 dgrad fused with GELU'
+    dy2 = _linear_backward(du, y2, bw.fc1, alpha, beta=beta)
+    dx1 = ops.layernorm_bwd(dy2, x1, bw.norm2.g, mean2, rstd2, bw.norm2.gg, bw.norm2.gb, dres=dx2, alpha=alpha,
+                            accumulate=acc)
+    do = _linear_backward(dx1, o, bw.proj, alpha, beta=beta)
     dqkv = torch.empty_like(qkv)
     for sg, lse in zip(segs, lses):
         ops.attn_bwd(_rows(qkv, sg), _rows(o, sg), _rows(do, sg), lse, sg.B, sg.S, heads, hd, scale,
                      out=_rows(dqkv, sg))
-    dy1 = _linear_backward(dqkv, y1, bw.qkv, alpha)
-    return ops.layernorm_bwd(dy1, x, bw.norm1.g, mean1, rstd1, bw.norm1.gg, bw.norm1.gb, dres=dx1, alpha=alpha)
+    dy1 = _linear_backward(dqkv, y1, bw.qkv, alpha, beta=beta)
+    return ops.layernorm_bwd(dy1, x, bw.norm1.g, mean1, rstd1, bw.norm1.gg, bw.norm1.gb, dres=dx1, alpha=alpha,
+                             accumulate=acc)
 
 
 # =============================================================================================== encoder
-def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], save: bool, final_norm=True):
+def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], save: bool, final_norm=True, ws_tag=None):
     """clips fp32 [B,3,T,H,W]; masks: None (all N tokens) or a list of int64 [B,K_i] index tensors.
     Returns (out [sum_i B*K_i, D] bf16, segs, saved).  With final_norm=False the last residual stream is returned
     (the target path fuses the final norm into vj_target_rows)."""
@@ -175,10 +189,13 @@ def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], sa
     x = ops.gemm_nt(tok, ew.patch.w, bias=ew.patch.b)
     for i, sg in enumerate(segs):
         ops.add_pos(_rows(x, sg), ew.pos, sg.B, sg.S, idx=None if masks is None else masks[i])
-    saved_blocks = []
-    for bw in ew.blocks:
-        x, sv = block_forward(x, bw, segs, ew.heads, save)
-        saved_blocks.append(sv)
+    if ws_tag is not None and USE_C_CHAIN:    # ws_tag: the caller owns one workspace per trunk (engine/chain.py)
+        x, saved_blocks = chain.blocks_forward(x, ew, segs, save, ws_tag, LN_EPS)
+    else:
+        saved_blocks = []
+        for bw in ew.blocks:
+            x, sv = block_forward(x, bw, segs, ew.heads, save)
+            saved_blocks.append(sv)
     if not final_norm:
         return x, segs, None
     out, mean, rstd = ops.layernorm_fwd(x, ew.norm.g, ew.norm.b, LN_EPS, save_stats=save)
@@ -186,23 +203,30 @@ def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], sa
     return out, segs, saved
 
 
-def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_done=None):
-    """dout [M, D] bf16: gradient of the encoder output rows.  Pixels need no gradient."""
+def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_done=None, beta: float = 0.0):
+    """dout [M, D] bf16: gradient of the encoder output rows.  Pixels need no gradient.  Parameter gradients are written
+    as alpha * grad + beta * old (beta = 1 accumulates micro-batches)."""
     tok, saved_blocks, xl, mean, rstd = saved
-    dx = ops.layernorm_bwd(dout, xl, ew.norm.g, mean, rstd, ew.norm.gg, ew.norm.gb, alpha=alpha)
-    for li in range(len(ew.blocks) - 1, -1, -1):
-        dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha)
-        saved_blocks[li] = None
-        if on_layer_done is not None:
-            on_layer_done("enc", li)          # bucket launch waits on the side stream's event, not on this stream
-    _linear_backward(dx, tok, ew.patch, alpha, need_dx=False)
+    dx = ops.layernorm_bwd(dout, xl, ew.norm.g, mean, rstd, ew.norm.gg, ew.norm.gb, alpha=alpha, accumulate=beta != 0.0)
+    if isinstance(saved_blocks, chain.TrunkCtx):
+        side = side_stream(dout.device)
+        dx = chain.blocks_backward(dx, saved_blocks, ew, alpha, side.stream.cuda_stream if side.enabled else None,
+                                   (lambda li: on_layer_done("enc", li)) if on_layer_done is not None else None,
+                                   beta_acc=beta)
+    else:
+        for li in range(len(ew.blocks) - 1, -1, -1):
+            dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha, beta)
+            saved_blocks[li] = None
+            if on_layer_done is not None:
+                on_layer_done("enc", li)      # bucket launch waits on the side stream's event, not on this stream
+    _linear_backward(dx, tok, ew.patch, alpha, need_dx=False, beta=beta)
     side_stream(dout.device).join()
     if on_layer_done is not None:
         on_layer_done("enc", -1)
 
 
 # =============================================================================================== predictor
-def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_pred, save: bool):
+def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_pred, save: bool, ws_tag=None):
     """z [sum_i B*Ke_i, D] bf16 (context-encoder output rows, per-mask segments enc_segs).
     Returns (zhat [sum_i B*Kp_i, D] bf16, tgt_segs, saved)."""
     Dp = pw.embed.w.shape[0]
@@ -221,10 +245,13 @@ def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_p
         # mask_index = i % num_mask_tokens (predictor.py:206; PredictorMultiMaskWrapper passes mask_index=i)
         ops.pred_assemble(_rows(e, sg), pw.mask_tokens[i % n_tok], pw.pos, masks_enc[i], masks_pred[i],
                           out=_rows(x, psg))
-    saved_blocks = []
-    for bw in pw.blocks:
-        x, sv = block_forward(x, bw, segs, pw.heads, save)
-        saved_blocks.append(sv)
+    if ws_tag is not None and USE_C_CHAIN:
+        x, saved_blocks = chain.blocks_forward(x, pw, segs, save, ws_tag, LN_EPS)
+    else:
+        saved_blocks = []
+        for bw in pw.blocks:
+            x, sv = block_forward(x, bw, segs, pw.heads, save)
+            saved_blocks.append(sv)
     # predictor_norm is row-wise and only target rows are projected (x[:, N_ctxt:], predictor.py:233-237):
     # normalise just those rows.
     t = torch.empty((rt, Dp), dtype=torch.bfloat16, device=dev)
@@ -236,37 +263,44 @@ def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_p
     return zhat, tsegs, saved
 
 
-def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_layer_done=None):
+def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_layer_done=None, beta: float = 0.0):
     """dzhat [sum_i B*Kp_i, D] bf16 -> returns dz [sum_i B*Ke_i, D] bf16 (gradient of the encoder output)."""
     z, e_shape, segs, tsegs, saved_blocks, t, tn, mean, rstd = saved
     Dp = pw.embed.w.shape[0]
     n_tok = len(pw.mask_tokens)
-    dtn = _linear_backward(dzhat, tn, pw.proj, alpha)
-    dt = ops.layernorm_bwd(dtn, t, pw.norm.g, mean, rstd, pw.norm.gg, pw.norm.gb, alpha=alpha)
+    acc = beta != 0.0
+    dtn = _linear_backward(dzhat, tn, pw.proj, alpha, beta=beta)
+    dt = ops.layernorm_bwd(dtn, t, pw.norm.g, mean, rstd, pw.norm.gg, pw.norm.gb, alpha=alpha, accumulate=acc)
     total = segs[-1].row0 + segs[-1].rows
     dx = torch.zeros((total, Dp), dtype=torch.bfloat16, device=dzhat.device)  # context rows start at zero grad
     for sg, psg, tsg in zip(enc_segs, segs, tsegs):
         ops.copy_rows(_rows(dt, tsg), _rows(dx, psg), psg.B, tsg.S, 0, psg.S, sg.S, tsg.S, Dp)
     if on_layer_done is not None:
         on_layer_done("pred", len(pw.blocks))
-    for li in range(len(pw.blocks) - 1, -1, -1):
-        dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha)
-        saved_blocks[li] = None
-        if on_layer_done is not None:
-            on_layer_done("pred", li)
+    if isinstance(saved_blocks, chain.TrunkCtx):
+        side = side_stream(dzhat.device)
+        dx = chain.blocks_backward(dx, saved_blocks, pw, alpha, side.stream.cuda_stream if side.enabled else None,
+                                   (lambda li: on_layer_done("pred", li)) if on_layer_done is not None else None,
+                                   beta_acc=beta)
+    else:
+        for li in range(len(pw.blocks) - 1, -1, -1):
+            dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha, beta)
+            saved_blocks[li] = None
+            if on_layer_done is not None:
+                on_layer_done("pred", li)
     # token assembly backward: mask-token grads = sum of the target rows; context rows flow to predictor_embed
     de = torch.empty(e_shape, dtype=torch.bfloat16, device=dzhat.device)
     used = set()
     for i, (sg, psg) in enumerate(zip(enc_segs, segs)):
         ti = i % n_tok
-        ops.colsum(_rows(dx, psg), pw.g_mask_tokens[ti], alpha=alpha, accumulate=ti in used, group=psg.S,
+        ops.colsum(_rows(dx, psg), pw.g_mask_tokens[ti], alpha=alpha, accumulate=(ti in used) or acc, group=psg.S,
                    row_lo=sg.S, row_hi=psg.S)
         used.add(ti)
         ops.copy_rows(_rows(dx, psg), _rows(de, sg), psg.B, psg.S, 0, sg.S, 0, sg.S, Dp)
     for ti in range(n_tok):
-        if ti not in used:
+        if ti not in used and not acc:
             pw.g_mask_tokens[ti].zero_()
-    dz = _linear_backward(de, z, pw.embed, alpha)
+    dz = _linear_backward(de, z, pw.embed, alpha, beta=beta)
     side_stream(dzhat.device).join()
     if on_layer_done is not None:
         on_layer_done("pred", -1)

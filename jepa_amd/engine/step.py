@@ -6,10 +6,12 @@ app/vjepa/train.py:414-487, executed by hand-written gfx950 kernels with no auto
     out = trainer.train_step(clips, masks_enc, masks_pred, lr=..., wd=..., ema=...)
     out.loss / out.loss_jepa / out.loss_reg                          # lazily synchronising floats
 
-Divergences from the reference that are deliberate: GradScaler is not emulated (bf16 has fp32's
-exponent range; the scaler's only observable effect is skipping a step on non-finite grads, which we keep as a
-device-side check when `check_finite=True`); the EMA skips the frozen pos_embed (m*x + (1-m)*x == x up to one
-rounding); both masks run through one fused chain.
+Divergences from the reference that are deliberate: GradScaler's loss scaling is not emulated (bf16
+has fp32's exponent range); its one observable effect -- skipping the optimizer step when a gradient is non-finite --
+is kept, always on, as a device-side flag that the fused AdamW kernel reads (no host sync); the EMA skips the frozen
+pos_embed (m*x + (1-m)*x == x up to one rounding); both masks run through one fused chain; a batch larger than
+`micro_batch` is processed in micro-batches with gradient accumulation (same sums, the collator still sees the whole
+batch).
 """
 import math
 from dataclasses import dataclass
@@ -17,7 +19,7 @@ from dataclasses import dataclass
 import torch
 
 from ..hip import ops
-from . import dp
+from . import dp, optstate
 from .layers import encoder_backward, encoder_forward, predictor_backward, predictor_forward, side_stream
 from .weights import ParamArena, encoder_views, is_no_decay, predictor_views
 
@@ -54,17 +56,17 @@ class _TargetArena:
 
 
 class StepOutput:
-    """Losses stay on the device until read (one host sync for all of them)."""
+    """Losses and gradient statistics stay on the device until read (one host sync for all of them)."""
 
-    def __init__(self, buf, reg_coeff, lr, wd, ema, grad_norms):
+    def __init__(self, buf, reg_coeff, lr, wd, ema, clipped, inv_world):
         self._buf, self._reg_coeff = buf, reg_coeff
         self.lr, self.wd, self.ema = lr, wd, ema
-        self.grad_norms = grad_norms
+        self._clipped, self._inv_world = clipped, inv_world
         self._host = None
 
     def _fetch(self):
         if self._host is None:
-            self._host = self._buf.tolist()
+            self._host = self._buf.tolist()   # [loss_jepa, loss_reg, -, -, sumsq_enc, bad_enc, sumsq_pred, bad_pred]
         return self._host
 
     @property
@@ -79,6 +81,23 @@ class StepOutput:
     def loss(self):
         return self.loss_jepa + self._reg_coeff * self.loss_reg
 
+    @property
+    def raw_grad_norms(self):
+        """(encoder, predictor) L2 norms of the averaged gradients of this step (before clipping)."""
+        h = self._fetch()
+        return (math.sqrt(h[4]) * self._inv_world, math.sqrt(h[6]) * self._inv_world)
+
+    @property
+    def grad_norms(self):
+        """What the reference logs (train.py:466-470): the clip_grad_norm_ results, 0 while clipping is inactive."""
+        return self.raw_grad_norms if self._clipped else (0.0, 0.0)
+
+    @property
+    def skipped(self):
+        """True when a non-finite gradient made the optimizer skip this step (GradScaler.step semantics)."""
+        h = self._fetch()
+        return (h[5] + h[7]) > 0
+
 
 def _strip(name):
     return name[len("backbone."):] if name.startswith("backbone.") else name
@@ -86,20 +105,26 @@ def _strip(name):
 
 class Trainer:
     def __init__(self, encoder, predictor, target_encoder, loss_exp=1.0, reg_coeff=0.0, betas=(0.9, 0.999),
-                 eps=1e-8, clip_grad=None, device=None, world_size=1, overlap_comm=True, check_finite=False):
+                 eps=1e-8, clip_grad=None, device=None, world_size=1, overlap_comm=True, check_finite=True,
+                 micro_batch=None):
         self.encoder, self.predictor, self.target_encoder = encoder, predictor, target_encoder
         self.vit, self.pred, self.tvit = encoder.backbone, predictor.backbone, target_encoder.backbone
         self.device = torch.device(device) if device is not None else next(encoder.parameters()).device
         if self.device.type != "cuda":
             raise ValueError("jepa_amd.Trainer needs a GPU device: the step runs in libvjepa_hip.so only")
+        if self.device.index is None:   # 'cuda' and 'cuda:0' must name the same streams / workspaces everywhere
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.micro_batch = micro_batch
         self.loss_exp, self.reg_coeff = float(loss_exp), float(reg_coeff)
         self.betas, self.eps, self.clip_grad = tuple(betas), float(eps), clip_grad
-        self.check_finite = check_finite
+        self.check_finite = True   # always on and device-side (the argument is kept for API compatibility)
         self.world_size = world_size
         dev = self.device
 
         enc_named = [("enc." + _strip(n), n, p) for n, p in encoder.named_parameters()]
         pred_named = [("pred." + _strip(n), n, p) for n, p in predictor.named_parameters()]
+        self._enc_named, self._pred_named = enc_named, pred_named
+        self._gs_desc = self._gs_meta = self._arena_stats = None
         # the four AdamW groups of init_opt (reference app/vjepa/utils.py:173-191)
         g_enc_d = [(a, p) for a, n, p in enc_named if p.requires_grad and not is_no_decay(n, p)]
         g_enc_n = [(a, p) for a, n, p in enc_named if p.requires_grad and is_no_decay(n, p)]
@@ -133,14 +158,20 @@ class Trainer:
         self.tw = encoder_views(self.tarena, "enc.", self.tvit,
                                 self.tarena.frozen["enc.pos_embed"].reshape(self.tvit.num_patches, -1), train=False)
         # optimizer-facing view (schedulers write lr / weight_decay into these dicts, like torch param_groups);
-        # order = the reference's: [enc decayed, pred decayed, enc no-decay, pred no-decay]
+        # order = the reference's: [enc decayed, pred decayed, enc no-decay, pred no-decay].  Like init_opt
+        # (app/vjepa/utils.py:173-191) the groups are built from ALL named_parameters, so the frozen pos_embed /
+        # predictor_pos_embed sit in groups 0 / 1 as stateless members: parameter ids in state_dict() then line up
+        # with a torch.optim.AdamW built by the reference.
+        def grp(named, nodecay):
+            return [p for _, n, p in named if is_no_decay(n, p) == nodecay]
         self.param_groups = [
-            {"params": [p for _, p in g_enc_d], "lr": 0.0, "weight_decay": 0.0, "_range": 0},
-            {"params": [p for _, p in g_pred_d], "lr": 0.0, "weight_decay": 0.0, "_range": 2},
-            {"params": [p for _, p in g_enc_n], "lr": 0.0, "weight_decay": 0, "WD_exclude": True, "_range": 1},
-            {"params": [p for _, p in g_pred_n], "lr": 0.0, "weight_decay": 0, "WD_exclude": True, "_range": 3},
+            {"params": grp(enc_named, False), "lr": 0.0, "weight_decay": 0.0, "_range": 0},
+            {"params": grp(pred_named, False), "lr": 0.0, "weight_decay": 0.0, "_range": 2},
+            {"params": grp(enc_named, True), "lr": 0.0, "weight_decay": 0, "WD_exclude": True, "_range": 1},
+            {"params": grp(pred_named, True), "lr": 0.0, "weight_decay": 0, "WD_exclude": True, "_range": 3},
         ]
-        self.opt_step = 0
+        self._slot_of = {id(sl.param): sl for sl in self.arena.slots.values()}
+        self._step_dev = torch.zeros(1, dtype=torch.float32, device=dev)   # Adam step count t (advanced on the device)
         self._stat = torch.zeros(8, dtype=torch.float32, device=dev)   # [loss_jepa, loss_reg, -, -, sq_enc, bad, sq_pred, bad]
         self.reducer = dp.GradReducer(self.arena, self.vit, self.pred, world_size, overlap=overlap_comm)
 
@@ -149,69 +180,89 @@ class Trainer:
     def forward_target(self, clips, masks_pred):
         """h_i = apply_masks(F.layer_norm(target_encoder(clips)), masks_pred)  (train.py:419-429), fp32."""
         B = clips.shape[0]
-        x, _, _ = encoder_forward(self.tw, clips, None, save=False, final_norm=False)
+        x, _, _ = encoder_forward(self.tw, clips, None, save=False, final_norm=False, ws_tag="tgt")
         N = self.tvit.num_patches
         return [ops.target_rows(x, self.tw.norm.g, self.tw.norm.b, mp, B, N, 1e-6, 1e-5) for mp in masks_pred]
 
     @torch.no_grad()
     def train_step(self, clips, masks_enc, masks_pred, lr, wd, ema, clip_now=False):
-        """One optimisation step.  clips fp32 [B,3,T,H,W]; masks_*: lists of int64 [B,K] (device tensors)."""
+        """One optimisation step.  clips fp32 [B,3,T,H,W]; masks_*: lists of int64 [B,K] (device tensors).
+        With `micro_batch` set and B larger, the batch is walked in micro-batches: gradients accumulate in the arena
+        (beta = 1 weight-gradient epilogues), losses accumulate on the device, one optimizer step at the end."""
         assert len(masks_enc) == len(masks_pred), 'Currently require num encoder masks = num predictor masks'
         B = clips.shape[0]
         D = self.vit.embed_dim
         n_masks = len(masks_pred)
         mark = self._phase_mark
         mark('start')
-        # ---- forward: the EMA target branch is independent of the context branch until the loss, so it runs on
-        #      the side stream concurrently (fills the tails of each other's kernels)
-        side = side_stream(self.device)
-        if side.enabled:
-            side.fork(clips, *masks_pred)
-            with torch.cuda.stream(side.stream):
-                h = self.forward_target(clips, masks_pred)
-        else:
-            h = self.forward_target(clips, masks_pred)
-        z, segs, saved_e = encoder_forward(self.ew, clips, masks_enc, save=True)
-        zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, masks_enc, masks_pred, save=True)
-        mark('context+predictor forward (main stream)')
-        if side.enabled:
-            side.join()
-            for t in h:
-                t.record_stream(torch.cuda.current_stream())
-        # ---- loss (train.py:440-459) and its gradient; |grad| carried as {+-s_i} in bf16, the common factor
-        #      alpha = 1/(numel_min * n_masks) is applied in fp32 where parameter gradients are written
-        numels = [t.rows * D for t in tsegs]
+        self._arena_stats = None
+        mb = B if not self.micro_batch else min(int(self.micro_batch), B)
+        chunks = [(c0, min(c0 + mb, B)) for c0 in range(0, B, mb)]
+        # loss normalisation over the WHOLE batch (train.py:440-446): mean over B*Kp_i*D elements per mask, / n_masks;
+        # |grad| is carried as {+-s_i} in bf16 and the common factor alpha is applied in fp32 where parameter
+        # gradients are written
+        numels = [B * mp.shape[1] * D for mp in masks_pred]
         nmin = min(numels)
         alpha = 1.0 / (nmin * n_masks)
-        dzhat = torch.empty_like(zhat)
-        pstd = torch.empty((B, D), dtype=torch.float32, device=self.device)
         with_reg = self.reg_coeff != 0.0
-        stats = [torch.empty((B, D, 2), dtype=torch.float32, device=self.device) if with_reg else None for _ in tsegs]
-        for i, t in enumerate(tsegs):
-            zi = zhat[t.row0:t.row0 + t.rows]
-            ops.latent_loss(zi, h[i], self._stat[0:1], p=self.loss_exp, out_scale=1.0 / (numels[i] * n_masks),
-                            accumulate=i > 0, dz=dzhat[t.row0:t.row0 + t.rows], gscale=nmin / numels[i])
-            ops.token_pstd(zi, pstd, B, t.S, D, accumulate=i > 0, stats=stats[i])
-        ops.reg_finish(pstd, n_masks, self._stat[1:2])
-        if with_reg:   # gradient of reg_coeff * mean(relu(1 - pstd)), expressed in the 1/alpha units dzhat carries
-            coef = self.reg_coeff / (B * D * n_masks) / alpha
-            for i, t in enumerate(tsegs):
-                ops.reg_grad(zhat[t.row0:t.row0 + t.rows], pstd, stats[i], dzhat[t.row0:t.row0 + t.rows], B, t.S, D,
-                             n_masks, coef)
-        mark('target forward joined + loss')
-        # ---- backward (predictor first, then encoder layers 23..0); gradient buckets go out as layers finish
+        pstd = torch.empty((B, D), dtype=torch.float32, device=self.device)
         side = side_stream(self.device)
-        self.reducer.begin(side.stream if side.enabled else None)
         hook = self.reducer.layer_done if self.reducer.enabled else None
-        dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=hook)
-        mark('predictor backward (main stream)')
-        encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=hook)
-        mark('encoder backward (main stream)')
+        for ci, (c0, c1) in enumerate(chunks):
+            last = ci == len(chunks) - 1
+            beta = 0.0 if ci == 0 else 1.0
+            cl = clips[c0:c1]
+            me = [m[c0:c1] for m in masks_enc] if len(chunks) > 1 else masks_enc
+            mp = [m[c0:c1] for m in masks_pred] if len(chunks) > 1 else masks_pred
+            me = [m if m.is_contiguous() else m.contiguous() for m in me]
+            mp = [m if m.is_contiguous() else m.contiguous() for m in mp]
+            Bc = c1 - c0
+            # ---- forward: the EMA target branch is independent of the context branch until the loss, so it runs on
+            #      the side stream concurrently (fills the tails of each other's kernels)
+            if side.enabled:
+                side.fork(cl, *mp)
+                with torch.cuda.stream(side.stream):
+                    h = self.forward_target(cl, mp)
+            else:
+                h = self.forward_target(cl, mp)
+            z, segs, saved_e = encoder_forward(self.ew, cl, me, save=True, ws_tag="enc_save")
+            zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, me, mp, save=True, ws_tag="pred_save")
+            mark('context+predictor forward (main stream)')
+            if side.enabled:
+                side.join()
+                for t in h:
+                    t.record_stream(torch.cuda.current_stream())
+            # ---- loss (train.py:440-459) and its gradient
+            dzhat = torch.empty_like(zhat)
+            stats = [torch.empty((Bc, D, 2), dtype=torch.float32, device=self.device) if with_reg else None
+                     for _ in tsegs]
+            for i, t in enumerate(tsegs):
+                zi = zhat[t.row0:t.row0 + t.rows]
+                ops.latent_loss(zi, h[i], self._stat[0:1], p=self.loss_exp, out_scale=1.0 / (numels[i] * n_masks),
+                                accumulate=(i > 0 or ci > 0), dz=dzhat[t.row0:t.row0 + t.rows], gscale=nmin / numels[i])
+                ops.token_pstd(zi, pstd[c0:c1], Bc, t.S, D, accumulate=i > 0, stats=stats[i])
+            if with_reg:   # gradient of reg_coeff * mean(relu(1 - pstd)), expressed in the 1/alpha units dzhat carries
+                coef = self.reg_coeff / (B * D * n_masks) / alpha
+                for i, t in enumerate(tsegs):
+                    ops.reg_grad(zhat[t.row0:t.row0 + t.rows], pstd[c0:c1], stats[i], dzhat[t.row0:t.row0 + t.rows], Bc,
+                                 t.S, D, n_masks, coef)
+            mark('target forward joined + loss')
+            # ---- backward (predictor first, then encoder layers L-1..0); on the last micro-batch the gradient
+            #      buckets go out as layers finish
+            if last:
+                self.reducer.begin(side.stream if side.enabled else None)
+            lhook = hook if last else None
+            dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=lhook, beta=beta)
+            mark('predictor backward (main stream)')
+            encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=lhook, beta=beta)
+            mark('encoder backward (main stream)')
+        ops.reg_finish(pstd, n_masks, self._stat[1:2])
         self.reducer.finish()
         # ---- clip / AdamW / EMA / bf16 re-cast (train.py:461-487)
-        norms = self.optimizer_step(lr, wd, ema, clip_now)
+        clipped = bool(clip_now and self.clip_grad is not None)
+        self.optimizer_step(lr, wd, ema, clip_now)
         mark('wgrad stream joined + AdamW/EMA')
-        return StepOutput(self._stat[:2].clone(), self.reg_coeff, lr, wd, ema, norms)
+        return StepOutput(self._stat.clone(), self.reg_coeff, lr, wd, ema, clipped, 1.0 / self.world_size)
 
     def _phase_mark(self, name):
         """Phase timestamps on the main stream (tools / bench diagnostics): set `self.phase_events = []` to collect
@@ -223,29 +274,32 @@ class Trainer:
             ev.append((name, e))
 
     # ------------------------------------------------------------------------------------------------ update
-    def _grad_sqnorms(self):
+    @property
+    def opt_step(self):
+        """Adam step count t (host view of the device counter; synchronises)."""
+        return int(self._step_dev.item())
+
+    @opt_step.setter
+    def opt_step(self, v):
+        self._step_dev.fill_(float(v))
+
+    def _enc_pred_ranges(self):
         A = self.arena
         (e0, _), (_, e1) = A.group_ranges[0], A.group_ranges[1]
         (p0, _), (_, p1) = A.group_ranges[2], A.group_ranges[3]
-        ops.sqnorm(A.G[e0:e1], self._stat[4:6])
-        ops.sqnorm(A.G[p0:p1], self._stat[6:8])
-        return self._stat[4:8].tolist()
+        return (e0, e1), (p0, p1)
 
     def optimizer_step(self, lr, wd, ema, clip_now=False):
+        """clip_grad_norm_ x2 (when active) + GradScaler's skip-on-non-finite + AdamW + EMA + bf16 re-casts, all decided
+        on the device: two sum-of-squares passes over the gradient arena feed the fused update kernel."""
         A = self.arena
         inv_world = 1.0 / self.world_size
-        scale_enc = scale_pred = inv_world
-        norms = (0.0, 0.0)
-        if (clip_now and self.clip_grad is not None) or self.check_finite:
-            sq_e, bad_e, sq_p, bad_p = self._grad_sqnorms()   # one host sync, like clip_grad_norm_'s float()
-            if self.check_finite and (bad_e + bad_p) > 0:
-                return (float("nan"), float("nan"))            # GradScaler semantics: skip the step on inf/nan
-            ne, npd = math.sqrt(sq_e) * inv_world, math.sqrt(sq_p) * inv_world
-            norms = (ne, npd)
-            if clip_now and self.clip_grad is not None:        # torch.nn.utils.clip_grad_norm_ coefficient
-                scale_enc *= min(1.0, self.clip_grad / (ne + 1e-6))
-                scale_pred *= min(1.0, self.clip_grad / (npd + 1e-6))
-        self.opt_step += 1
+        (e0, e1), (p0, p1) = self._enc_pred_ranges()
+        ops.sqnorm(A.G[e0:e1], self._stat[4:6])
+        ops.sqnorm(A.G[p0:p1], self._stat[6:8])
+        gstat = self._stat[4:8]
+        ops.step_advance(gstat, self._step_dev)
+        clip = float(self.clip_grad) if (clip_now and self.clip_grad is not None) else 0.0
         b1, b2 = self.betas
         T = self.tarena
         for gi, (lo, hi) in enumerate(A.group_ranges):
@@ -255,14 +309,40 @@ class Trainer:
             decay = wd if gi in (0, 2) else 0.0
             tgt = T.P[lo - T.lo:hi - T.lo] if is_enc else None
             tgtb = T.Pb[lo - T.lo:hi - T.lo] if is_enc else None
-            ops.adamw_ema(A.P[lo:hi], A.G[lo:hi], A.M1[lo:hi], A.M2[lo:hi], A.Pb[lo:hi], tgt, tgtb, lr, decay, b1, b2,
-                          self.eps, self.opt_step, scale_enc if is_enc else scale_pred, ema)
+            ops.adamw_ema_guarded(A.P[lo:hi], A.G[lo:hi], A.M1[lo:hi], A.M2[lo:hi], A.Pb[lo:hi], tgt, tgtb, lr, decay, b1,
+                                  b2, self.eps, inv_world, ema, gstat, 0 if is_enc else 1, clip, inv_world,
+                                  self._step_dev)
         A.refresh_transposed()
         for g in self.param_groups:
             g["lr"] = lr
             if not g.get("WD_exclude", False):
                 g["weight_decay"] = wd
-        return norms
+
+    # ------------------------------------------------------------------------------------------------ logging
+    def arena_stats(self):
+        """Per-tensor gradient norms and Adam-moment magnitudes of the step that just ran: one launch over the arenas
+        (vj_grad_stats_multi) + one copy.  {'enc'|'pred': {'grads': [(name, norm, is_matrix)], 'moments': [(mean|m|,
+        mean|v|)]}}; gradients are the data-parallel averages (what DDP leaves in p.grad, train.py:476-479).
+        Cached until the next train_step."""
+        if self._arena_stats is not None:
+            return self._arena_stats
+        if self._gs_desc is None:
+            order = [("enc", a, n, p) for a, n, p in self._enc_named if p.requires_grad]
+            order += [("pred", a, n, p) for a, n, p in self._pred_named if p.requires_grad]
+            self._gs_meta = [(which, n, self.arena.slots[a].numel, not is_no_decay(n, p)) for which, a, n, p in order]
+            flat = []
+            for which, a, n, p in order:
+                flat += [self.arena.slots[a].off, self.arena.slots[a].numel]
+            self._gs_desc = torch.tensor(flat, dtype=torch.int64, device=self.device)
+        A = self.arena
+        sums = ops.grad_stats_multi(A.G, A.M1, A.M2, self._gs_desc, len(self._gs_meta)).tolist()
+        inv_world = 1.0 / self.world_size
+        out = {"enc": {"grads": [], "moments": []}, "pred": {"grads": [], "moments": []}}
+        for (which, n, numel, is_mat), (sq, a1, a2) in zip(self._gs_meta, sums):
+            out[which]["grads"].append((n, math.sqrt(sq) * inv_world, is_mat))
+            out[which]["moments"].append((a1 / numel, a2 / numel))
+        self._arena_stats = out
+        return out
 
     def zero_grad(self, set_to_none=False):
         """Gradients are fully overwritten by every backward (beta = 0 wgrads); kept for API compatibility."""
@@ -270,37 +350,16 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------------------ checkpoints
     def state_dict(self):
-        """torch.optim.AdamW-compatible optimizer state (reference checkpoint key 'opt', train.py:331-342)."""
-        state, groups, k = {}, [], 0
-        b1, b2 = self.betas
-        for g in self.param_groups:
-            ids = []
-            for p in g["params"]:
-                s = next(sl for sl in self.arena.slots.values() if sl.param is p)
-                state[k] = {"step": torch.tensor(float(self.opt_step)),
-                            "exp_avg": self.arena.M1[s.off:s.off + s.numel].view(s.shape).clone(),
-                            "exp_avg_sq": self.arena.M2[s.off:s.off + s.numel].view(s.shape).clone()}
-                ids.append(k)
-                k += 1
-            gd = {kk: v for kk, v in g.items() if kk not in ("params", "_range")}
-            gd.update({"params": ids, "betas": (b1, b2), "eps": self.eps, "amsgrad": False, "maximize": False,
-                       "foreach": None, "capturable": False, "differentiable": False, "fused": None})
-            groups.append(gd)
-        return {"state": state, "param_groups": groups}
+        """torch.optim.AdamW-compatible optimizer state (reference checkpoint key 'opt', train.py:331-342): parameter ids
+        count every member of the reference's four groups (frozen position tables included, stateless)."""
+        return optstate.build_state_dict(self.param_groups, self._slot_of, self.arena.M1, self.arena.M2, self.opt_step,
+                                         self.betas, self.eps)
 
     def load_state_dict(self, sd):
-        k = 0
-        for g, gs in zip(self.param_groups, sd["param_groups"]):
-            for p in g["params"]:
-                s = next(sl for sl in self.arena.slots.values() if sl.param is p)
-                st = sd["state"].get(k)
-                if st is not None:
-                    self.arena.M1[s.off:s.off + s.numel].copy_(st["exp_avg"].reshape(-1))
-                    self.arena.M2[s.off:s.off + s.numel].copy_(st["exp_avg_sq"].reshape(-1))
-                    self.opt_step = int(float(st["step"]))
-                k += 1
-            g["lr"] = gs.get("lr", g["lr"])
-            g["weight_decay"] = gs.get("weight_decay", g["weight_decay"])
+        """Accepts our own state_dict() and the 'opt' entry of a reference checkpoint (same grouping and ids)."""
+        step = optstate.load_state_dict(self.param_groups, self._slot_of, self.arena.M1, self.arena.M2, sd)
+        if step is not None:
+            self.opt_step = step
 
     def sync_shadows(self):
         """Call after writing parameters from outside (load_state_dict): refresh bf16 / transposed shadows."""

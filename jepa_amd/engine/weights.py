@@ -18,16 +18,7 @@ import torch
 
 from ..hip import ops
 
-ALIGN = 64
-
-
-def _pad(n):
-    return (n + ALIGN - 1) // ALIGN * ALIGN
-
-
-def is_no_decay(name, p):
-    """Group split of init_opt (reference app/vjepa/utils.py:173-191)."""
-    return ("bias" in name) or (p.dim() == 1)
+from .optstate import ALIGN, Slot as _Slot, is_no_decay, layout, pad64 as _pad  # noqa: F401  (pure, CPU-testable)
 
 
 # ----------------------------------------------------------------------------------------------- view structs
@@ -82,30 +73,13 @@ class PredictorW:
 
 
 # ----------------------------------------------------------------------------------------------- arena
-@dataclass
-class _Slot:
-    name: str
-    off: int
-    numel: int
-    shape: tuple
-    param: torch.nn.Parameter
-
-
 class ParamArena:
     """Flat fp32 master/grad/moment arenas + bf16 shadows for a list of (name, Parameter) groups."""
 
     def __init__(self, groups, device, with_moments=True, bind_grads=True):
         """groups: list of lists of (name, param); each group becomes one contiguous, 64-padded range."""
         self.device = device
-        self.slots = {}
-        self.group_ranges = []
-        off = 0
-        for grp in groups:
-            start = off
-            for name, p in grp:
-                self.slots[name] = _Slot(name, off, p.numel(), tuple(p.shape), p)
-                off += _pad(p.numel())
-            self.group_ranges.append((start, off))
+        self.slots, self.group_ranges, off = layout(groups)
         self.total = off
         self.P = torch.zeros(off, dtype=torch.float32, device=device)
         self.G = torch.zeros(off, dtype=torch.float32, device=device)

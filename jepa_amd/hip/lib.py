@@ -18,6 +18,29 @@ I64 = ctypes.c_int64
 I32 = ctypes.c_int
 F32 = ctypes.c_float
 
+
+
+class VjLinear(ctypes.Structure):           # vj_linear_t
+    _fields_ = [("w", P), ("b", P), ("wT", P), ("ldwT", I64), ("gw", P), ("gb", P), ("n_out", I64), ("k_in", I64)]
+
+
+class VjNorm(ctypes.Structure):             # vj_norm_t
+    _fields_ = [("g", P), ("b", P), ("gg", P), ("gb", P)]
+
+
+class VjBlock(ctypes.Structure):            # vj_block_t
+    _fields_ = [("norm1", VjNorm), ("qkv", VjLinear), ("proj", VjLinear), ("norm2", VjNorm), ("fc1", VjLinear),
+                ("fc2", VjLinear)]
+
+
+class VjSeg(ctypes.Structure):              # vj_seg_t
+    _fields_ = [("row0", I64), ("B", I64), ("S", I64)]
+
+
+LAYER_CB = ctypes.CFUNCTYPE(None, P, I32)   # vj_layer_cb_t
+F64P = ctypes.POINTER(ctypes.c_double)
+I64P = ctypes.POINTER(ctypes.c_int64)
+
 # name -> (restype, argtypes); mirrors include/vjepa_hip.h one to one
 SIGNATURES = {
     "vj_abi_version": (I32, []),
@@ -52,10 +75,22 @@ SIGNATURES = {
     "vj_reg_grad": (I32, [P, P, P, P, I64, I64, I64, I64, F32, P]),
     "vj_reg_finish": (I32, [P, I64, I64, P, P]),
     "vj_adamw_ema": (I32, [P, P, P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, F32, P]),
+    "vj_step_advance": (I32, [P, P, P]),
+    "vj_adamw_ema_guarded": (I32, [P, P, P, P, P, P, P, I64, F32, F32, F32, F32, F32, F32, F32, P, I32, F32, F32, P, P]),
+    "vj_grad_stats_chunks": (I64, []),
+    "vj_grad_stats_multi": (I32, [P, P, P, P, I64, P, P]),
     "vj_ema_update": (I32, [P, P, P, I64, F32, P]),
     "vj_cast_f32_to_bf16": (I32, [P, P, I64, P]),
     "vj_sqnorm_ws_bytes": (I64, []),
     "vj_sqnorm_f32": (I32, [P, I64, P, I32, P, I64, P]),
+    "vj_blocks_fwd_ws_bytes": (I64, [I64, I64, I64, I64, I64, I32]),
+    "vj_blocks_fwd": (I32, [ctypes.POINTER(VjBlock), I64, P, P, I64, I64, I64, ctypes.POINTER(VjSeg), I64, F32, I32, P,
+                            I64, P]),
+    "vj_blocks_bwd_ws_bytes": (I64, [I64, I64, I64, I64]),
+    "vj_blocks_bwd": (I32, [ctypes.POINTER(VjBlock), I64, P, P, P, I64, I64, I64, ctypes.POINTER(VjSeg), I64, F32, F32,
+                            P, I64, P, I64, I32, P, P, LAYER_CB, P]),
+    "vj_prof_enable": (I32, [I32]),
+    "vj_prof_collect": (I32, [F64P, F64P, I64P, ctypes.c_char_p]),
     "vj_probe_tr16": (I32, [P, I32, P]),
     "vj_probe_copy": (I32, [P, P, I64, P]),
 }

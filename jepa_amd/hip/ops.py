@@ -45,15 +45,23 @@ def _req(t, dtype, name):
 
 
 class Scratch:
-    """Per-device scratch workspace reused by kernels that need partial-sum buffers."""
+    """Per-(device, tag, STREAM) scratch workspace for kernels that need partial-sum buffers.  The step runs kernels
+    on two streams at once (dgrad chain / weight gradients), so two launches of the same kernel family may be in
+    flight together: each stream gets its own buffer.  A buffer is only replaced (regrown) after a device-wide
+    synchronise, so no enqueued kernel can still be using the old allocation."""
 
     _bufs = {}
 
     @classmethod
-    def get(cls, nbytes, device, tag="default"):
-        key = (str(device), tag)
+    def get(cls, nbytes, device, tag="default", stream=None):
+        global _dev_index
+        if _dev_index is None:
+            _dev_index = torch.cuda.current_device()
+        key = (_dev_index, tag, _raw_stream(_dev_index) if stream is None else stream)
         buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                torch.cuda.synchronize()
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             cls._bufs[key] = buf
         return buf
@@ -144,7 +152,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, alpha=1.0,
     rows, D = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty_like(x)
     nws = lib.vj_layernorm_bwd_ws_bytes(D)
-    ws = Scratch.get(nws, x.device, "ln")
+    ws = Scratch.get(nws, x.device, "ln", stream=stream)
     check(lib.vj_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
                                _ptr(dgamma), _ptr(dbeta), alpha, 1.0 if accumulate else 0.0, rows, D, _ptr(ws), nws,
                                _stream(stream)), "vj_layernorm_bwd")
@@ -197,7 +205,7 @@ def gemm_wgrad(dyT, xT, out, alpha=1.0, beta=0.0, flags=None, stream=None):
     lib = load_library()
     M, K = dyT.shape
     N = xT.shape[0]
-    ws = Scratch.get(WGRAD_WS_BYTES, dyT.device, "wgrad")
+    ws = Scratch.get(WGRAD_WS_BYTES, dyT.device, "wgrad", stream=stream)
     _ev = _timed("gemm_nt", 2.0 * M * N * K)
     check(lib.vj_gemm_bf16_nt_splitk(_ptr(dyT), dyT.stride(0), _ptr(xT), xT.stride(0), _ptr(out), out.stride(0), M, N,
                                      K, alpha, beta, GEMM_FLAGS if flags is None else flags, _ptr(ws), WGRAD_WS_BYTES,
@@ -214,7 +222,7 @@ def gemm_wgrad_tn(dy, x, out, alpha=1.0, beta=0.0, stream=None):
     _req(x, BF16, "x")
     T, N1 = dy.shape
     N2 = x.shape[1]
-    ws = Scratch.get(WGRAD_WS_BYTES, dy.device, "wgrad")
+    ws = Scratch.get(WGRAD_WS_BYTES, dy.device, "wgrad", stream=stream)
     _ev = _timed("gemm_nt", 2.0 * T * N1 * N2)
     check(lib.vj_gemm_bf16_tn_splitk(_ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(out), out.stride(0), T, N1, N2,
                                      alpha, beta, _ptr(ws), WGRAD_WS_BYTES, _stream(stream)), "vj_gemm_bf16_tn_splitk")
@@ -231,7 +239,7 @@ def transpose_colsum(x, colsum_out, alpha=1.0, accumulate=False, stream=None):
     Mp = pad64(M)
     out = torch.empty((N, Mp), dtype=BF16, device=x.device)
     nws = lib.vj_transpose_colsum_ws_bytes(M, N)
-    ws = Scratch.get(nws, x.device, "tcolsum")
+    ws = Scratch.get(nws, x.device, "tcolsum", stream=stream)
     check(lib.vj_transpose_colsum_bf16(_ptr(x), _ptr(out), M, N, x.stride(0), Mp, _ptr(colsum_out), alpha,
                                        1.0 if accumulate else 0.0, _ptr(ws), nws, _stream(stream)),
           "vj_transpose_colsum_bf16")
@@ -267,7 +275,7 @@ def colsum(x, out, M=None, alpha=1.0, accumulate=False, group=0, row_lo=0, row_h
     M = x.shape[0] if M is None else M
     N = x.shape[1]
     nws = lib.vj_colsum_ws_bytes(N)
-    ws = Scratch.get(nws, x.device, "colsum")
+    ws = Scratch.get(nws, x.device, "colsum", stream=stream)
     if group <= 0:
         group, row_lo, row_hi = max(M, 1), 0, max(M, 1)
     check(lib.vj_colsum_bf16(_ptr(x), M, N, x.stride(0), group, row_lo, row_hi, _ptr(out), alpha,
@@ -294,7 +302,7 @@ def attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
     _req(dout, BF16, "dout")
     dqkv = torch.empty_like(qkv) if out is None else out
     nws = lib.vj_attn_bwd_ws_bytes(B, S, H)
-    ws = Scratch.get(nws, qkv.device, "attn")
+    ws = Scratch.get(nws, qkv.device, "attn", stream=stream)
     _ev = _timed("attn_bwd", 8.0 * B * H * S * S * hd)
     check(lib.vj_attn_bwd(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), B, S, H, hd, scale, _ptr(ws), nws,
                           _stream(stream)), "vj_attn_bwd")
@@ -334,7 +342,7 @@ def latent_loss(z, h, loss_out, p=1.0, out_scale=1.0, accumulate=False, dz=None,
     _req(z, BF16, "z")
     _req(h, F32, "h")
     nws = lib.vj_latent_loss_ws_bytes()
-    ws = Scratch.get(nws, z.device, "loss")
+    ws = Scratch.get(nws, z.device, "loss", stream=stream)
     check(lib.vj_latent_loss(_ptr(z), _ptr(h), _ptr(dz), z.numel(), p, gscale, out_scale, int(accumulate),
                              _ptr(loss_out), _ptr(ws), nws, _stream(stream)), "vj_latent_loss")
     return loss_out
@@ -364,6 +372,31 @@ def adamw_ema(p, g, m, v, p_bf16, tgt, tgt_bf16, lr, wd, beta1, beta2, eps, step
                            lr, wd, beta1, beta2, eps, step, gscale, ema, _stream(stream)), "vj_adamw_ema")
 
 
+def step_advance(gstat, step_dev, stream=None):
+    check(load_library().vj_step_advance(_ptr(gstat), _ptr(step_dev), _stream(stream)), "vj_step_advance")
+
+
+def adamw_ema_guarded(p, g, m, v, p_bf16, tgt, tgt_bf16, lr, wd, beta1, beta2, eps, gscale, ema, gstat, sel, clip,
+                      norm_scale, step_dev, stream=None):
+    """AdamW + EMA + bf16 re-casts with the skip-on-non-finite flag, the clip coefficient and the step count read on
+    the device (include/vjepa_hip.h: vj_adamw_ema_guarded)."""
+    lib = load_library()
+    check(lib.vj_adamw_ema_guarded(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), _ptr(tgt), _ptr(tgt_bf16), p.numel(),
+                                   lr, wd, beta1, beta2, eps, gscale, ema, _ptr(gstat), sel, clip, norm_scale,
+                                   _ptr(step_dev), _stream(stream)), "vj_adamw_ema_guarded")
+
+
+def grad_stats_multi(G, M1, M2, desc, n_tensors, stream=None):
+    """One launch over the arenas -> fp32 [n_tensors, 3] = per-tensor {sum g^2, sum |exp_avg|, sum |exp_avg_sq|}
+    (device tensor; reading it is the only host sync)."""
+    lib = load_library()
+    nch = lib.vj_grad_stats_chunks()
+    out = torch.empty((n_tensors, nch, 3), dtype=F32, device=G.device)
+    check(lib.vj_grad_stats_multi(_ptr(G), _ptr(M1), _ptr(M2), _ptr(desc), n_tensors, _ptr(out), _stream(stream)),
+          "vj_grad_stats_multi")
+    return out.sum(dim=1)
+
+
 def ema_update(tgt, src, tgt_bf16, m, stream=None):
     lib = load_library()
     check(lib.vj_ema_update(_ptr(tgt), _ptr(src), _ptr(tgt_bf16), tgt.numel(), m, _stream(stream)), "vj_ema_update")
@@ -378,7 +411,7 @@ def cast_bf16(src, dst, stream=None):
 def sqnorm(g, out2, accumulate=False, stream=None):
     lib = load_library()
     nws = lib.vj_sqnorm_ws_bytes()
-    ws = Scratch.get(nws, g.device, "sqnorm")
+    ws = Scratch.get(nws, g.device, "sqnorm", stream=stream)
     check(lib.vj_sqnorm_f32(_ptr(g), g.numel(), _ptr(out2), int(accumulate), _ptr(ws), nws, _stream(stream)),
           "vj_sqnorm_f32")
     return out2

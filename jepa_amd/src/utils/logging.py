@@ -1,7 +1,9 @@
 """Timers, meters and CSV logging with the reference's names (src/utils/logging.py:14-118).
 
-grad_logger / adamw_logger read the flat gradient / moment arenas when the trainer exposes them, so the
-~1k per-tensor host syncs of the reference collapse into a handful of reductions evaluated only when logged.
+`grad_logger` / `adamw_logger` accept the fused Trainer (engine/step.py): every per-tensor statistic then comes from
+ONE `vj_grad_stats_multi` launch over the flat gradient / moment arenas and one small device-to-host copy, evaluated
+only when a log line is due -- the reference pays a `float()` host sync per tensor (~1000 per step).  Given plain
+named parameters / a torch optimizer (CPU tensors, the oracle) they fall back to per-tensor reductions.
 """
 import logging
 import sys
@@ -64,27 +66,33 @@ class AverageMeter(object):
         self.avg = self.sum / self.count
 
 
-def grad_logger(named_params):
-    stats = AverageMeter()
-    stats.first_layer = stats.last_layer = None
-    for n, p in named_params:
-        if (p.grad is not None) and not (n.endswith('.bias') or len(p.shape) == 1):
-            g = float(torch.norm(p.grad.data))
-            stats.update(g)
-            if 'qkv' in n:
-                stats.last_layer = g
-                if stats.first_layer is None:
-                    stats.first_layer = g
-    if stats.first_layer is None or stats.last_layer is None:
-        stats.first_layer = stats.last_layer = 0.
+def _meter_from(values):
+    m = AverageMeter()
+    for v in values:
+        m.update(v)
+    return m
+
+
+def grad_logger(source, which=None):
+    """Norms of the weight-matrix gradients: mean/min/max over tensors plus the first and last qkv layer.
+    source: the fused Trainer (with which='enc' | 'pred') or an iterable of (name, parameter)."""
+    if hasattr(source, 'arena_stats'):
+        rows = [(n, g) for n, g, is_mat in source.arena_stats()[which]['grads'] if is_mat]
+    else:
+        rows = [(n, float(torch.norm(p.grad.data))) for n, p in source
+                if (p.grad is not None) and not (n.endswith('.bias') or len(p.shape) == 1)]
+    stats = _meter_from(g for _, g in rows)
+    qkv = [g for n, g in rows if 'qkv' in n]
+    stats.first_layer, stats.last_layer = (qkv[0], qkv[-1]) if qkv else (0., 0.)
     return stats
 
 
 def adamw_logger(optimizer):
+    """Mean magnitude of the first / second Adam moments per tensor (mean/min/max over tensors)."""
+    if hasattr(optimizer, 'arena_stats'):
+        st = optimizer.arena_stats()
+        rows = st['enc']['moments'] + st['pred']['moments']
+        return {'exp_avg': _meter_from(a for a, _ in rows), 'exp_avg_sq': _meter_from(b for _, b in rows)}
     state = optimizer.state_dict().get('state')
-    exp_avg, exp_avg_sq = AverageMeter(), AverageMeter()
-    for key in state:
-        s = state.get(key)
-        exp_avg.update(float(s.get('exp_avg').mean()))
-        exp_avg_sq.update(float(s.get('exp_avg_sq').mean()))
-    return {'exp_avg': exp_avg, 'exp_avg_sq': exp_avg_sq}
+    return {'exp_avg': _meter_from(float(s.get('exp_avg').abs().mean()) for s in state.values()),
+            'exp_avg_sq': _meter_from(float(s.get('exp_avg_sq').abs().mean()) for s in state.values())}

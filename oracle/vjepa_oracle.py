@@ -7,8 +7,9 @@ bench.py's cpu_baseline leg may import it.  Nothing under jepa_amd/ imports this
 thing measured or shipped.
 
 Pinning: the reference ships no tests or golden vectors ("parity unpinned" upstream).  This restatement is pinned
-by (a) tests/golden/micro_step.npz, generated by oracle/make_golden.py from the *real* reference modules run in
-the build container, and (b) tests/test_oracle_vs_reference.py, which imports /root/reference live when present.
+by tests/test_oracle_golden.py against tests/golden/micro_step.npz and tests/golden/host_tables.npz, which
+oracle/make_golden.py generates from the *real* reference modules run in the build container (re-running that
+script against /root/reference reproduces both files bit for bit).
 
 Each function cites the reference lines it follows (paths relative to the reference root).
 """
@@ -235,9 +236,9 @@ def adamw_update(p, g, state, lr, wd, beta1, beta2, eps, step):
     p.addcdiv_(m, denom, value=-lr / bc1)
 
 
-def train_step(state, clips, masks_enc, masks_pred, cfg, hp, step):
-    """One full step on `state` = dict(enc=, pred=, tgt=, opt={name:(m,v)}) of fp32 CPU tensors (updated in
-    place).  `step` is 1-based.  Returns a dict of checkpoints for parity tests."""
+def step_grads(state, clips, masks_enc, masks_pred, cfg, hp):
+    """Forward + loss + backward of train.py:419-464 on one batch: returns (checkpoints, grads) without touching
+    `state`.  grads = {"enc": {name: g}, "pred": {name: g}}."""
     enc_w = {k: v.detach().clone().requires_grad_(k != "pos_embed") for k, v in state["enc"].items()}
     pred_w = {k: v.detach().clone().requires_grad_(k != "predictor_pos_embed") for k, v in state["pred"].items()}
     h_list, z_enc, z_list = forward_all(enc_w, pred_w, state["tgt"], clips, masks_enc, masks_pred, cfg)
@@ -246,9 +247,29 @@ def train_step(state, clips, masks_enc, masks_pred, cfg, hp, step):
     loss.backward()
     grads = {"enc": {k: v.grad for k, v in enc_w.items() if v.grad is not None},
              "pred": {k: v.grad for k, v in pred_w.items() if v.grad is not None}}
+    out = {"loss": float(loss.detach()), "loss_jepa": float(loss_jepa.detach()), "loss_reg": float(loss_reg.detach()),
+           "h": h_list, "z_enc": [z.detach() for z in z_enc], "z": [z.detach() for z in z_list]}
+    return out, grads
+
+
+def apply_update(state, grads, hp, step, clip_now=False):
+    """clip_grad_norm_ (train.py:466-470, per module, only when active) + AdamW (train.py:471-475 via
+    app/vjepa/utils.py:173-194) + EMA (train.py:483-487) on `state`, in place.  Returns (lr, wd, ema, norms)."""
     lr = lr_at(step, int(hp["warmup"] * hp["ipe"]), hp["start_lr"], hp["lr"], hp["final_lr"],
                int(hp["ipe_scale"] * hp["epochs"] * hp["ipe"]))
     wd = wd_at(step, hp["wd"], hp["final_wd"], int(hp["ipe_scale"] * hp["epochs"] * hp["ipe"]))
+    norms = (0.0, 0.0)
+    if clip_now and hp.get("clip_grad") is not None:
+        # torch.nn.utils.clip_grad_norm_ operates on .grad of parameters: wrap the gradient tensors accordingly
+        ns = []
+        for grp in ("enc", "pred"):
+            ps = []
+            for g in grads[grp].values():
+                p = torch.nn.Parameter(torch.empty(0))
+                p.grad = g            # clipped in place
+                ps.append(p)
+            ns.append(float(torch.nn.utils.clip_grad_norm_(ps, hp["clip_grad"])))
+        norms = tuple(ns)
     with torch.no_grad():
         for grp in ("enc", "pred"):
             for name, p in state[grp].items():
@@ -261,10 +282,40 @@ def train_step(state, clips, masks_enc, masks_pred, cfg, hp, step):
         m = ema_at(step - 1, hp["ema"][0], hp["ema"][1], hp["ipe"], hp["epochs"], hp["ipe_scale"])
         for name, pk in state["tgt"].items():  # train.py:486-487 (frozen pos_embed rides along)
             pk.mul_(m).add_((1.0 - m) * state["enc"][name])
-    return {"loss": float(loss.detach()), "loss_jepa": float(loss_jepa.detach()), "loss_reg": float(loss_reg.detach()),
-            "lr": lr, "wd": wd,
-            "ema": m, "h": h_list, "z_enc": [z.detach() for z in z_enc], "z": [z.detach() for z in z_list],
-            "grads": grads}
+    return lr, wd, m, norms
+
+
+def train_step(state, clips, masks_enc, masks_pred, cfg, hp, step, clip_now=False):
+    """One full step on `state` = dict(enc=, pred=, tgt=, opt={name:(m,v)}) of fp32 CPU tensors (updated in
+    place).  `step` is 1-based.  Returns a dict of checkpoints for parity tests."""
+    out, grads = step_grads(state, clips, masks_enc, masks_pred, cfg, hp)
+    raw = {grp: {k: v.clone() for k, v in gs.items()} for grp, gs in grads.items()} if clip_now else grads
+    lr, wd, m, norms = apply_update(state, grads, hp, step, clip_now)
+    out.update({"lr": lr, "wd": wd, "ema": m, "grads": raw, "grad_norms": norms})
+    return out
+
+
+def train_step_dp(state, rank_batches, cfg, hp, step, clip_now=False):
+    """The same step under DistributedDataParallel (train.py:295-297): every rank runs forward/backward on its own
+    (clips, masks_enc, masks_pred) and the gradients are AVERAGED over ranks before clip / AdamW / EMA; the loss each
+    rank logs is its own.  rank_batches: list of (clips, masks_enc, masks_pred), one per rank."""
+    outs, acc = [], None
+    for clips, me, mp in rank_batches:
+        o, g = step_grads(state, clips, me, mp, cfg, hp)
+        outs.append(o)
+        if acc is None:
+            acc = {grp: {k: v.clone() for k, v in gs.items()} for grp, gs in g.items()}
+        else:
+            for grp in acc:
+                for k in acc[grp]:
+                    acc[grp][k] += g[grp][k]
+    W = len(rank_batches)
+    for grp in acc:
+        for k in acc[grp]:
+            acc[grp][k] /= W
+    raw = {grp: {k: v.clone() for k, v in gs.items()} for grp, gs in acc.items()}
+    lr, wd, m, norms = apply_update(state, acc, hp, step, clip_now)
+    return {"ranks": outs, "lr": lr, "wd": wd, "ema": m, "grads": raw, "grad_norms": norms}
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -238,7 +238,12 @@ def sdpa_ref(qkv, B, S, H, hd):
 
 
 ATTN_SHAPES = [(2, 20, 3, 64), (2, 64, 3, 32), (1, 107, 16, 64), (2, 366, 16, 64), (1, 1568, 4, 64),
-               (2, 300, 16, 24), (1, 1113, 4, 24), (1, 200, 2, 80), (3, 52, 3, 32), (1, 129, 2, 128)]
+               (2, 300, 16, 24), (1, 1113, 4, 24), (1, 200, 2, 80), (3, 52, 3, 32), (1, 129, 2, 128),
+               # ViT-H head_dim 80 on the native 96-wide class (3 k-steps, 5 output tiles): ragged, multi-tile, and the
+               # full 384^2 x 16 frame sequence of BASELINE configs[4] (8 x 24 x 24 = 4608 tokens, 16 heads)
+               (2, 63, 16, 80), (1, 1568, 2, 80), (1, 4608, 16, 80), (2, 577, 3, 72),
+               # head_dim 24 / 32 on the re-swizzled 64-byte-row images: tile boundaries +-1
+               (1, 64, 2, 24), (1, 65, 2, 24), (2, 127, 2, 32), (1, 1208, 16, 24)]
 
 
 @pytest.mark.parametrize("B,S,H,hd", ATTN_SHAPES)

@@ -1,0 +1,331 @@
+"""Round-2 GPU tests of the step engine: C launch chains, micro-batching, the device-side step guard (non-finite skip,
+clipping), logging statistics, optimizer-state compatibility, the input prefetcher, data-parallel numerics on one GPU,
+and the stand-alone module forwards.  Stated tolerances are next to each assertion."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.golden_util import HP, rel_l2  # noqa: E402
+from tests.step_util import (TINY, TINY_MASKS, build_models, build_trainer, draw_batch, oracle_cfg,  # noqa: E402
+                             to_dev)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _gens(masks=TINY_MASKS, m=TINY):
+    from oracle import vjepa_oracle as O
+    return O.make_mask_gens(masks, m["crop"], m["frames"], m["patch"], m["tubelet"])
+
+
+# ------------------------------------------------------------------------------------------------ launch chains
+def test_c_chain_is_bit_identical_to_python_chain():
+    """vj_blocks_fwd / vj_blocks_bwd enqueue the same kernels in the same order as the per-kernel Python chain:
+    losses, every gradient and every updated weight must be BIT-identical (split-K is deterministic)."""
+    from jepa_amd.engine import layers
+    gens = _gens()
+    res = {}
+    for use_c in (True, False):
+        layers.USE_C_CHAIN = use_c
+        try:
+            tr, _, _, _, _ = build_trainer(TINY, 2)
+            for step in range(1, 3):
+                clips, me, mp = draw_batch(gens, 4, TINY, 10 + step, 20 + step)
+                out = tr.train_step(*to_dev(clips, me, mp), lr=1e-3, wd=0.04, ema=0.99)
+            res[use_c] = (out.loss, tr.arena.G.clone(), tr.arena.P.clone(), tr.tarena.P.clone())
+        finally:
+            layers.USE_C_CHAIN = True
+    assert res[True][0] == res[False][0]
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert torch.equal(a, b)
+
+
+def test_micro_batches_accumulate_to_the_full_batch_gradient():
+    """B=6 in micro-batches of 2 == one batch of 6: same activations per sample, fp32 gradient sums in a different
+    order -> rel-L2 <= 1e-5 on the whole gradient arena, loss equal to 1e-6 relative."""
+    gens = _gens()
+    clips, me, mp = draw_batch(gens, 6, TINY, 31, 32)
+    outs = []
+    for mb in (None, 2, 4):   # 4: uneven last micro-batch (4 + 2)
+        tr, _, _, _, _ = build_trainer(TINY, 2, perturb_small=True, micro_batch=mb)
+        o = tr.train_step(*to_dev(clips, me, mp), lr=1e-3, wd=0.04, ema=0.99)
+        outs.append((o.loss, o.loss_reg, tr.arena.G.clone(), tr.arena.P.clone()))
+    for loss, reg, G, P in outs[1:]:
+        assert abs(loss - outs[0][0]) <= 1e-6 * abs(outs[0][0]), (loss, outs[0][0])
+        assert abs(reg - outs[0][1]) <= 1e-5 * abs(outs[0][1]) + 1e-7
+        assert rel_l2(G.cpu(), outs[0][2].cpu()) < 1e-5, rel_l2(G.cpu(), outs[0][2].cpu())
+        assert rel_l2(P.cpu(), outs[0][3].cpu()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ step guard
+def test_nonfinite_gradient_skips_the_update_on_the_device():
+    """GradScaler.step semantics (train.py:471): a NaN/inf gradient anywhere -> no AdamW for ANY parameter, the Adam
+    step count does not advance, the EMA still runs; decided inside the kernel (no host sync in optimizer_step)."""
+    gens = _gens()
+    tr, _, _, _, _ = build_trainer(TINY, 2)
+    clips, me, mp = draw_batch(gens, 2, TINY, 41, 42)
+    tr.train_step(*to_dev(clips, me, mp), lr=1e-3, wd=0.04, ema=0.9)
+    assert tr.opt_step == 1
+    P0, M0, T0 = tr.arena.P.clone(), tr.arena.M1.clone(), tr.tarena.P.clone()
+    G_ok = tr.arena.G.clone()
+    tr.arena.G[tr.arena.slots["pred.predictor_proj.weight"].off + 3] = float("nan")   # poison ONE predictor gradient
+    tr.optimizer_step(1e-3, 0.04, 0.9)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.arena.P, P0) and torch.equal(tr.arena.M1, M0), "weights / moments must be untouched"
+    assert tr.opt_step == 1, "the Adam step count must not advance on a skipped step"
+    lo, hi = tr.tarena.lo, tr.tarena.hi
+    exp = T0 * 0.9 + (1 - 0.9) * P0[lo:hi]
+    assert torch.allclose(tr.tarena.P, exp, rtol=0, atol=1e-7), "EMA runs against the unchanged weights"
+    # and a clean gradient steps again
+    tr.arena.G.copy_(G_ok)
+    tr.optimizer_step(1e-3, 0.04, 0.9)
+    assert tr.opt_step == 2 and not torch.equal(tr.arena.P, P0)
+
+
+def test_clip_active_step_vs_oracle_clip_grad_norm():
+    """epoch > warmup path (train.py:466-470): per-module clip_grad_norm_(clip_grad) computed on the device vs
+    torch.nn.utils.clip_grad_norm_ in the oracle.  clip_grad is set far below the real norms so the coefficient matters.
+    Norms within 2e-2 relative (bf16 gradients), updated weights within 2.5*lr per element."""
+    from oracle import vjepa_oracle as O
+    gens = _gens()
+    clip = 0.02
+    tr, state, _, _, _ = build_trainer(TINY, 2, perturb_small=True, clip_grad=clip)
+    hp = dict(HP, clip_grad=clip)
+    cfg = oracle_cfg(TINY, 2)
+    for step in range(1, 3):
+        clips, me, mp = draw_batch(gens, 2, TINY, 51 + step, 52 + step)
+        ref = O.train_step(state, clips, me, mp, cfg, hp, step, clip_now=True)
+        out = tr.train_step(*to_dev(clips, me, mp), lr=ref["lr"], wd=ref["wd"], ema=ref["ema"], clip_now=True)
+        assert ref["grad_norms"][0] > 3 * clip and ref["grad_norms"][1] > 3 * clip, "test setup: clipping must be active"
+        for a, b in zip(out.grad_norms, ref["grad_norms"]):
+            assert abs(a - b) < 2e-2 * b, (out.grad_norms, ref["grad_norms"])
+        assert abs(out.loss - ref["loss"]) < 1e-3 * abs(ref["loss"])
+    for name in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc2.weight", "norm.weight"):
+        w = tr.arena.f32("enc." + name).cpu()
+        assert (w - state["enc"][name]).abs().max() <= 2.5 * ref["lr"] + 1e-7, name
+        assert rel_l2(w, state["enc"][name]) < 2e-3
+    w = tr.arena.f32("pred.predictor_proj.weight").cpu()
+    assert rel_l2(w, state["pred"]["predictor_proj.weight"]) < 2e-3
+    # without clip_now the reference logs zeros (train.py:466-467)
+    clips, me, mp = draw_batch(gens, 2, TINY, 60, 61)
+    out = tr.train_step(*to_dev(clips, me, mp), lr=1e-4, wd=0.04, ema=0.99, clip_now=False)
+    assert out.grad_norms == (0.0, 0.0) and out.raw_grad_norms[0] > 0
+
+
+# ------------------------------------------------------------------------------------------------ logging
+def test_arena_stats_match_per_tensor_reductions():
+    """grad_logger / adamw_logger over ONE vj_grad_stats_multi launch == the reference's per-tensor float() loop
+    (src/utils/logging.py:91-118) run on the same gradients / moments: 1e-5 relative."""
+    from jepa_amd.src.utils.logging import adamw_logger, grad_logger
+    gens = _gens()
+    tr, _, enc, pred, _ = build_trainer(TINY, 2, perturb_small=True)
+    clips, me, mp = draw_batch(gens, 2, TINY, 71, 72)
+    tr.train_step(*to_dev(clips, me, mp), lr=1e-3, wd=0.04, ema=0.99)
+    for which, mod in (("enc", enc), ("pred", pred)):
+        fused = grad_logger(tr, which)
+        plain = grad_logger(mod.named_parameters())       # p.grad are views of the gradient arena
+        for f in ("avg", "min", "max", "first_layer", "last_layer"):
+            a, b = getattr(fused, f), getattr(plain, f)
+            assert abs(a - b) <= 1e-5 * abs(b) + 1e-12, (which, f, a, b)
+        assert fused.count == plain.count
+    fused = adamw_logger(tr)
+    sd = tr.state_dict()
+
+    class _Opt:
+        def state_dict(self):
+            return sd
+    plain = adamw_logger(_Opt())
+    for k in ("exp_avg", "exp_avg_sq"):
+        for f in ("avg", "min", "max"):
+            a, b = getattr(fused[k], f), getattr(plain[k], f)
+            assert abs(a - b) <= 1e-5 * abs(b) + 1e-15, (k, f, a, b)
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+def test_optimizer_state_roundtrip_through_torch_adamw():
+    """Trainer.state_dict() loads into a torch.optim.AdamW built exactly like the reference's init_opt
+    (app/vjepa/utils.py:173-194, ALL named parameters incl. the frozen position tables) and comes back unchanged."""
+    from jepa_amd.engine import optstate
+    gens = _gens()
+    tr, _, enc, pred, _ = build_trainer(TINY, 2)
+    clips, me, mp = draw_batch(gens, 2, TINY, 81, 82)
+    tr.train_step(*to_dev(clips, me, mp), lr=1e-3, wd=0.04, ema=0.99)
+    sd = tr.state_dict()
+    groups = [dict(g, params=[p for _, p in ps]) for g, ps in
+              optstate.reference_groups(enc.named_parameters(), pred.named_parameters())]
+    ref_opt = torch.optim.AdamW(groups)
+    ref_opt.load_state_dict(sd)                       # raises on any group-size / id mismatch
+    n_state = sum(1 for g in ref_opt.param_groups for p in g["params"] if p in ref_opt.state)
+    n_train = sum(1 for m in (enc, pred) for p in m.parameters() if p.requires_grad)
+    assert n_state == n_train
+    for g in ref_opt.param_groups:
+        for p in g["params"]:
+            if p in ref_opt.state:
+                s = tr._slot_of[id(p)]
+                assert torch.equal(ref_opt.state[p]["exp_avg"].reshape(-1), tr.arena.M1[s.off:s.off + s.numel])
+    # frozen tables are members (stateless) of groups 0 / 1, like the reference
+    assert any(not p.requires_grad for p in ref_opt.param_groups[0]["params"])
+    assert any(not p.requires_grad for p in ref_opt.param_groups[1]["params"])
+    back = ref_opt.state_dict()
+    M1 = tr.arena.M1.clone()
+    tr.arena.M1.zero_()
+    tr.load_state_dict(back)
+    assert torch.equal(tr.arena.M1, M1) and tr.opt_step == 1
+    # a mismatching checkpoint must raise BEFORE anything is written (no silent partial load)
+    bad = {"state": back["state"], "param_groups": [dict(g) for g in back["param_groups"]]}
+    bad["param_groups"][0] = dict(bad["param_groups"][0], params=bad["param_groups"][0]["params"][1:])
+    with pytest.raises(ValueError):
+        tr.load_state_dict(bad)
+    assert torch.equal(tr.arena.M1, M1)
+
+
+# ------------------------------------------------------------------------------------------------ input edge
+def test_device_prefetcher_delivers_every_batch_in_order():
+    """Pinned double-buffered H2D on a copy stream: contents bit-exact, order preserved, slots safely reused while a
+    consumer kernel is still running on the compute stream."""
+    from jepa_amd.engine.input import DevicePrefetcher
+    host = []
+    g = torch.Generator().manual_seed(3)
+    for i in range(7):
+        host.append(([torch.randn(2, 3, 4, 16, 16, generator=g)], [torch.randint(0, 50, (2, 5 + i))],
+                     [torch.randint(0, 50, (2, 9))]))
+    it = iter(host)
+    pf = DevicePrefetcher(lambda: next(it), torch.device(DEV), batch_size=2, num_clips=1)
+    busy = torch.randn(4096, 4096, device=DEV)
+    for i in range(7):
+        clips, me, mp = pf.next()
+        acc = clips.clone()
+        for _ in range(3):
+            busy = busy @ busy * 1e-3            # keep the compute stream busy while the next copy is in flight
+        acc2 = clips.clone()                     # read again AFTER the busy work: the slot must not have been overwritten
+        torch.cuda.synchronize()
+        assert torch.equal(acc.cpu(), host[i][0][0]) and torch.equal(acc2.cpu(), host[i][0][0])
+        assert torch.equal(me[0].cpu(), host[i][1][0]) and torch.equal(mp[0].cpu(), host[i][2][0])
+    assert pf.bytes_copied > 0
+
+
+# ------------------------------------------------------------------------------------------------ data parallel
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        import torch.distributed as dist
+        from oracle import vjepa_oracle as O
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # gloo all-reduces device tensors via the host
+        from jepa_amd.engine import dp
+        tr, state, _, _, _ = build_trainer(TINY, 2, perturb_small=True, world_size=world)
+        dp.broadcast_parameters(tr.arena, tr.tarena)
+        gens = _gens()
+        hp = dict(HP)
+        cfg = oracle_cfg(TINY, 2)
+        for step in range(1, 3):
+            batches = [draw_batch(gens, 2, TINY, 100 * step + r, 200 * step + r) for r in range(world)]
+            ref = O.train_step_dp(state, batches, cfg, hp, step) if rank == 0 else None
+            clips, me, mp = batches[rank]                    # different clips AND different mask sizes per rank
+            lr = O.lr_at(step, int(hp["warmup"] * hp["ipe"]), hp["start_lr"], hp["lr"], hp["final_lr"],
+                         int(hp["ipe_scale"] * hp["epochs"] * hp["ipe"]))
+            wd = O.wd_at(step, hp["wd"], hp["final_wd"], int(hp["ipe_scale"] * hp["epochs"] * hp["ipe"]))
+            ema = O.ema_at(step - 1, hp["ema"][0], hp["ema"][1], hp["ipe"], hp["epochs"], hp["ipe_scale"])
+            out = tr.train_step(*to_dev(clips, me, mp), lr=lr, wd=wd, ema=ema)
+            loss = out.loss
+            if rank == 0:
+                assert abs(loss - ref["ranks"][0]["loss"]) < 1e-3 * abs(ref["ranks"][0]["loss"])
+                inv = 1.0 / world
+                for grp, name in (("enc", "blocks.5.attn.qkv.weight"), ("enc", "patch_embed.proj.weight"),
+                                  ("pred", "predictor_blocks.1.mlp.fc1.weight"), ("enc", "blocks.0.norm1.weight"),
+                                  ("pred", "mask_tokens.0"), ("pred", "predictor_embed.bias")):
+                    g = tr.arena.grad(grp + "." + name).float().cpu() * inv        # arena holds the SUM over ranks
+                    r = ref["grads"][grp][name].reshape(g.shape)
+                    assert rel_l2(g, r) < 8e-2, (step, grp, name, rel_l2(g, r))
+        # every rank holds the same weights after the averaged update
+        mine = tr.arena.P.clone()
+        other = mine.clone()
+        dist.broadcast(other, 0)
+        assert torch.equal(mine, other), "ranks diverged"
+        if rank == 0:
+            for name in ("blocks.3.mlp.fc1.weight", "blocks.11.attn.proj.weight"):
+                w = tr.arena.f32("enc." + name).cpu()
+                assert (w - state["enc"][name]).abs().max() <= 2.5 * lr + 1e-7
+                assert rel_l2(w, state["enc"][name]) < 2e-3
+            assert len(tr.reducer.launched) == len(tr.reducer.buckets) + len(tr.reducer.tail)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_on_one_gpu_matches_oracle_with_averaged_gradients():
+    """DDP numerics (train.py:295-297) before an 8-GPU box exists: two processes on cuda:0, gloo backend, different
+    clips and different mask sizes per rank; the bucketed reducer runs its real hook / stream / event path.  Gradients
+    (arena SUM / world) vs the oracle's rank-averaged gradients: rel-L2 <= 8e-2; weights equal across ranks bit for bit
+    and within 2.5*lr of the oracle's."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(560)
+    msgs = [q.get(timeout=10) for _ in range(2)]
+    assert all(m[1] == "ok" for m in msgs), msgs
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+# ------------------------------------------------------------------------------------------------ module forwards
+def test_standalone_block_forwards_match_torch():
+    """MLP / Attention / Block / PatchEmbed3D.forward (inference, no grad) vs the same arithmetic in fp32 torch:
+    rel-L2 <= 1.5e-2 (bf16 operands)."""
+    import torch.nn.functional as F
+    from jepa_amd.src.models.utils.modules import Block
+    from jepa_amd.src.models.utils.patch_embed import PatchEmbed3D
+    torch.manual_seed(0)
+    blk = Block(dim=128, num_heads=4, mlp_ratio=4.0, qkv_bias=True,
+                norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6)).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    x = torch.randn(3, 70, 128, device=DEV)
+
+    def ref_attn(a, t):
+        B, N, C = t.shape
+        qkv = F.linear(t, a.qkv.weight, a.qkv.bias).reshape(B, N, 3, a.num_heads, C // a.num_heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, N, C)
+        return F.linear(o, a.proj.weight, a.proj.bias)
+
+    def ref_mlp(m, t):
+        return F.linear(F.gelu(F.linear(t, m.fc1.weight, m.fc1.bias)), m.fc2.weight, m.fc2.bias)
+
+    with torch.no_grad():
+        r_attn, r_mlp = ref_attn(blk.attn, x), ref_mlp(blk.mlp, x)
+        y = x + ref_attn(blk.attn, blk.norm1(x))
+        r_blk = y + ref_mlp(blk.mlp, blk.norm2(y))
+        assert rel_l2(blk.attn(x).cpu(), r_attn.cpu()) < 1.5e-2
+        assert rel_l2(blk.mlp(x).cpu(), r_mlp.cpu()) < 1.5e-2
+        assert rel_l2(blk(x).cpu(), r_blk.cpu()) < 1.5e-2
+        pe = PatchEmbed3D(patch_size=16, tubelet_size=2, in_chans=3, embed_dim=64).to(DEV)
+        clip = torch.randn(2, 3, 4, 32, 32, device=DEV)
+        r_pe = pe.proj(clip).flatten(2).transpose(1, 2)
+        assert rel_l2(pe(clip).cpu(), r_pe.cpu()) < 1.5e-2
+    with pytest.raises(NotImplementedError):
+        blk(x)                                            # grad mode: the stand-alone forward refuses
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            blk.cpu()(x.cpu())                            # and there is no CPU path
