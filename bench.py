@@ -231,12 +231,16 @@ def main():
     sync()
     log("warm-up done; timing")
     t0 = time.perf_counter()
+    t_first = None
     for i in range(args.warmup, n_total):
         last = run(i)
+        if t_first is None:   # the first step is enqueued against an idle GPU: pure host cost, no queue back-pressure
+            t_first = time.perf_counter() - t0
     host_enqueue = time.perf_counter() - t0
     sync()
     elapsed = time.perf_counter() - t0
-    log(f"host enqueue time {1e3 * host_enqueue / args.steps:.1f} ms/step (GPU step {1e3 * elapsed / args.steps:.1f} ms)")
+    log(f"host enqueue time {1e3 * host_enqueue / args.steps:.1f} ms/step incl. queue back-pressure, "
+        f"{1e3 * t_first:.1f} ms for the first step (GPU step {1e3 * elapsed / args.steps:.1f} ms)")
     if trainer.reducer.enabled:   # self-diagnosis of the scaling run: how long the compute stream waited on RCCL
         ex = trainer.reducer.exposed_ms()
         if ex is not None:

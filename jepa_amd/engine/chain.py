@@ -61,7 +61,8 @@ class Workspace:
             if buf is not None:
                 torch.cuda.synchronize(device)
                 cls._bufs[key] = buf = None
-            buf = torch.empty(int(nbytes * 1.1) + 256, dtype=torch.uint8, device=device)
+            # 30 % headroom: sequence lengths change with every mask draw, and every regrowth costs a device-wide sync
+            buf = torch.empty(int(nbytes * 1.3) + 256, dtype=torch.uint8, device=device)
             cls._bufs[key] = buf
         return buf
 

@@ -265,7 +265,7 @@ def apply_update(state, grads, hp, step, clip_now=False):
         for grp in ("enc", "pred"):
             ps = []
             for g in grads[grp].values():
-                p = torch.nn.Parameter(torch.empty(0))
+                p = torch.nn.Parameter(torch.zeros_like(g))
                 p.grad = g            # clipped in place
                 ps.append(p)
             ns.append(float(torch.nn.utils.clip_grad_norm_(ps, hp["clip_grad"])))

@@ -27,10 +27,10 @@ def test_c_chain_is_bit_identical_to_python_chain():
     """vj_blocks_fwd / vj_blocks_bwd enqueue the same kernels in the same order as the per-kernel Python chain:
     losses, every gradient and every updated weight must be BIT-identical (split-K is deterministic)."""
     from jepa_amd.engine import layers
-    gens = _gens()
     res = {}
     for use_c in (True, False):
         layers.USE_C_CHAIN = use_c
+        gens = _gens()    # fresh generators: their step counters seed the block sizes (multiblock3d.py:114-128)
         try:
             tr, _, _, _, _ = build_trainer(TINY, 2)
             for step in range(1, 3):
@@ -47,8 +47,7 @@ def test_c_chain_is_bit_identical_to_python_chain():
 def test_micro_batches_accumulate_to_the_full_batch_gradient():
     """B=6 in micro-batches of 2 == one batch of 6: same activations per sample, fp32 gradient sums in a different
     order -> rel-L2 <= 1e-5 on the whole gradient arena, loss equal to 1e-6 relative."""
-    gens = _gens()
-    clips, me, mp = draw_batch(gens, 6, TINY, 31, 32)
+    clips, me, mp = draw_batch(_gens(), 6, TINY, 31, 32)
     outs = []
     for mb in (None, 2, 4):   # 4: uneven last micro-batch (4 + 2)
         tr, _, _, _, _ = build_trainer(TINY, 2, perturb_small=True, micro_batch=mb)
@@ -79,7 +78,8 @@ def test_nonfinite_gradient_skips_the_update_on_the_device():
     assert tr.opt_step == 1, "the Adam step count must not advance on a skipped step"
     lo, hi = tr.tarena.lo, tr.tarena.hi
     exp = T0 * 0.9 + (1 - 0.9) * P0[lo:hi]
-    assert torch.allclose(tr.tarena.P, exp, rtol=0, atol=1e-7), "EMA runs against the unchanged weights"
+    assert torch.allclose(tr.tarena.P, exp, rtol=1e-6, atol=1e-7), "EMA runs against the unchanged weights"
+    assert not torch.equal(tr.tarena.P, T0)
     # and a clean gradient steps again
     tr.arena.G.copy_(G_ok)
     tr.optimizer_step(1e-3, 0.04, 0.9)
@@ -92,7 +92,7 @@ def test_clip_active_step_vs_oracle_clip_grad_norm():
     Norms within 2e-2 relative (bf16 gradients), updated weights within 2.5*lr per element."""
     from oracle import vjepa_oracle as O
     gens = _gens()
-    clip = 0.02
+    clip = 5e-4      # the gradient norms of this config are ~3e-3 (the loss is a mean over ~1e5 elements)
     tr, state, _, _, _ = build_trainer(TINY, 2, perturb_small=True, clip_grad=clip)
     hp = dict(HP, clip_grad=clip)
     cfg = oracle_cfg(TINY, 2)

@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jepa_amd.hip import ops  # noqa: E402
 
 SHAPES = [("tgt", 24, 1568, 16, 64), ("ctx m0", 24, 366, 16, 64), ("ctx m1", 24, 107, 16, 64),
-          ("prd m0", 24, 1113, 16, 24), ("prd m1", 24, 1208, 16, 24), ("vith", 8, 1568, 16, 80)]
+          ("prd m0", 24, 1113, 16, 24), ("prd m1", 24, 1208, 16, 24), ("vith", 8, 1568, 16, 80),
+          ("vith384", 2, 4608, 16, 80)]
 
 
 def main():
