@@ -35,17 +35,24 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, obj, headers):
+def _compile(src, obj, headers, extra=()):
     if not _newer(obj, [src, os.path.abspath(__file__)] + headers):
         return obj, False
-    cmd = [_hipcc()] + CXXFLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
+    cmd = [_hipcc()] + CXXFLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + list(extra) + ["-x", "hip", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
     return obj, True
 
 
-def build(verbose=True, force=False):
+def build(verbose=True, force=False, variant=None, extra_flags=()):
+    """variant: build an A/B copy `libvjepa_hip_<variant>.so` with extra compiler flags (objects in _build_<variant>);
+    selected at run time with VJ_LIB_VARIANT=<variant> (jepa_amd/hip/lib.py).  Experiments only: the product is the
+    default library."""
+    global OBJ, LIB
+    if variant:
+        OBJ = os.path.join(CSRC, "_build_" + variant)
+        LIB = os.path.join(LIBDIR, f"libvjepa_hip_{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
@@ -56,7 +63,7 @@ def build(verbose=True, force=False):
     jobs = [(s, os.path.join(OBJ, os.path.splitext(os.path.basename(s))[0] + ".o")) for s in srcs]
     rebuilt = False
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-        for obj, did in ex.map(lambda j: _compile(j[0], j[1], headers), jobs):
+        for obj, did in ex.map(lambda j: _compile(j[0], j[1], headers, extra_flags), jobs):
             rebuilt |= did
             if verbose and did:
                 print(f"[jepa_amd.build] compiled {os.path.basename(obj)}", flush=True)
@@ -73,4 +80,6 @@ def build(verbose=True, force=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    _args = [a for a in sys.argv[1:] if a != "--force"]
+    _variant = _args[0] if _args else None          # python -m jepa_amd.build [variant [extra hipcc flags...]]
+    build(force="--force" in sys.argv, variant=_variant, extra_flags=_args[1:])

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <vector>
 #include <string>
+#include <cstdlib>
 
 #define CH(call)              \
   do {                        \
@@ -139,11 +140,14 @@ extern "C" int vj_prof_collect(double* ms, double* flop, int64_t* launches, cons
 }
 
 // ---------------------------------------------------------------------------------------------------- launch helpers
+// GEMM kernel-selection flags per role (experiments: VJ_GEMM_FWD_FLAGS / VJ_GEMM_DGRAD_FLAGS, e.g. 256 = gemm4w.hip)
+static int g_fwd_flags = [] { const char* e = getenv("VJ_GEMM_FWD_FLAGS"); return e ? atoi(e) : 0; }();
+static int g_dgrad_flags = [] { const char* e = getenv("VJ_GEMM_DGRAD_FLAGS"); return e ? atoi(e) : 0; }();
 static int gemm(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                 int64_t K, const float* bias, const void* res, int64_t ldr, const void* aux_in, void* aux_out,
-                int64_t ldaux, int epi, hipStream_t st) {
+                int64_t ldaux, int epi, hipStream_t st, int flags = 0) {
   ProfScope ps(st, 0, 2.0 * M * N * K, M, N, K, epi);
-  return vj_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, res, ldr, aux_in, aux_out, ldaux, epi, 1.0f, 0.0f, 0, st);
+  return vj_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, res, ldr, aux_in, aux_out, ldaux, epi, 1.0f, 0.0f, flags, st);
 }
 
 struct FwdLayout {
@@ -232,7 +236,7 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
     float* mean2 = save ? (float*)(w + L.mean2) : nullptr;
     float* rstd2 = save ? (float*)(w + L.rstd2) : nullptr;
     CH(vj_layernorm_fwd(x, b.norm1.g, b.norm1.b, w + L.y1, mean1, rstd1, M, D, ln_eps, stream));
-    CH(gemm(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 0, stream));
+    CH(gemm(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_fwd_flags));
     for (int64_t s = 0; s < n_segs; s++) {
       const vj_seg_t& sg = segs[s];
       if (sg.B * sg.S == 0) continue;
@@ -241,11 +245,11 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
       CH(vj_attn_fwd(w + L.qkv + sg.row0 * 3 * D * 2, w + L.o + sg.row0 * D * 2, lse, sg.B, sg.S, heads, hd, scale,
                      stream));
     }
-    CH(gemm(w + L.o, D, b.proj.w, D, w + L.x1, D, M, D, D, b.proj.b, x, D, nullptr, nullptr, 0, 0, stream));
+    CH(gemm(w + L.o, D, b.proj.w, D, w + L.x1, D, M, D, D, b.proj.b, x, D, nullptr, nullptr, 0, 0, stream, g_fwd_flags));
     CH(vj_layernorm_fwd(w + L.x1, b.norm2.g, b.norm2.b, w + L.y2, mean2, rstd2, M, D, ln_eps, stream));
     CH(gemm(w + L.y2, D, b.fc1.w, D, w + L.g, Dh, M, Dh, D, b.fc1.b, nullptr, 0, nullptr, save ? w + L.u : nullptr, Dh,
-            1, stream));
-    CH(gemm(w + L.g, Dh, b.fc2.w, Dh, x2, D, M, D, Dh, b.fc2.b, w + L.x1, D, nullptr, nullptr, 0, 0, stream));
+            1, stream, g_fwd_flags));
+    CH(gemm(w + L.g, Dh, b.fc2.w, Dh, x2, D, M, D, Dh, b.fc2.b, w + L.x1, D, nullptr, nullptr, 0, 0, stream, g_fwd_flags));
     x = x2;
   }
   return 0;
@@ -368,15 +372,15 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     if (sc.side != sc.main && li + 2 < n_blocks) HIPCH(hipStreamWaitEvent(stream, side_done[li + 2], 0), "vj_blocks_bwd");
     // fc2: dgrad fused with GELU' ; wgrad reads (dx2, g)
     CH(wgrad(sc, dx2, w + F.g, b.fc2));
-    CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream));
+    CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream, g_dgrad_flags));
     // fc1
     CH(wgrad(sc, du, w + F.y2, b.fc1));
-    CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream));
+    CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     CH(vj_layernorm_bwd(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
                         dx1, b.norm2.gg, b.norm2.gb, alpha, beta_acc, M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
     // proj
     CH(wgrad(sc, dx1, w + F.o, b.proj));
-    CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream));
+    CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     for (int64_t s = 0; s < n_segs; s++) {
       const vj_seg_t& sg = segs[s];
       if (sg.B * sg.S == 0) continue;
@@ -388,7 +392,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     // qkv
     CH(wgrad(sc, dqkv, w + F.y1, b.qkv));
     CH(gemm(dqkv, 3 * D, b.qkv.wT, b.qkv.ldwT, tmp + L.dy1, D, M, D, 3 * D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0,
-            stream));
+            stream, g_dgrad_flags));
     CH(vj_layernorm_bwd(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
                         b.norm1.gg, b.norm1.gb, alpha, beta_acc, M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
     if (sc.side != sc.main) {

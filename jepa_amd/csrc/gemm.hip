@@ -262,6 +262,7 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
 //        bits 6-7 = pipeline (0 auto, 1 = BK64 double buffer, 2 = BK32 4-stage ring with counted vmcnt,
 //                   3 = 256x256 staggered 8-phase schedule, gemm8.hip)
 int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);  // gemm8.hip
+int vj_gemm_launch_4w(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);      // gemm4w.hip
 
 template <int EPI>
 static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
@@ -269,10 +270,22 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
   int cfg = (flags >> 4) & 3;
   int pipe = (flags >> 6) & 3;
   const bool is_wgrad = (EPI == EPI_F32 && ws != nullptr);
+  // bit 8: the 4-wave 256x128 kernel with two workgroups per CU (gemm4w.hip)
+  if ((flags & 0x100) && a.K % 64 == 0 && !reg_staged) return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
   if (pipe == 0 && cfg == 0) {
     // measured on the ViT-L step shapes (tools/gemm_bench.py): the staggered 8-phase 256x256 kernel wins on every
-    // forward / dgrad shape with >= ~90 tiles except the N=1152, K=384 predictor qkv; split-K wgrads (few tiles,
-    // long K) stay on 128x128 with 2 workgroups per CU.
+    // forward / dgrad shape with >= ~90 tiles; split-K wgrads (few tiles, long K) stay on 128x128 with 2 workgroups
+    // per CU.  The 4-wave 256x128 kernel with two workgroups per CU (gemm4w.hip) is FASTER in isolation on most step
+    // shapes (+35 % on the K = N = 1024 projection, +32 % predictor qkv, +17 % patch embed / context qkv: the tile-fixed
+    // costs hide under the co-resident workgroup) and makes a single-stream step 1.9 % faster, but the training step
+    // runs two HIP streams, where the other stream's kernels already fill the 8-phase kernel's idle CUs, and half-CU
+    // workgroups then share CUs with attention / LayerNorm workgroups at half of their tuned occupancy: same-box A/B
+    // 87.0 ms (8-phase) vs 90.0 ms (4-wave) per step, for every selection policy tried.  So it is opt-in: flags bit 8 or
+    // VJ_GEMM_4W=1 (all forward / dgrad GEMMs), meant for single-stream use (inference, profiling).
+    const int64_t t4w = cdiv64(a.M, 256) * cdiv64(a.N, 128);
+    static const int use_4w = [] { const char* e = getenv("VJ_GEMM_4W"); return e ? atoi(e) : 0; }();
+    if (use_4w == 1 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 64)
+      return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
     if (!is_wgrad && a.K % 64 == 0 && t256 >= 90) pipe = 3;
     if (is_wgrad && a.K % 64 == 0 && t256 >= 40) pipe = 3;   // qkv/fc1/fc2 wgrads: 8-phase + split-K (0.97-1.08 vs 0.78-0.96 PF)

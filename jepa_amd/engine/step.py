@@ -99,6 +99,10 @@ class StepOutput:
         return (h[5] + h[7]) > 0
 
 
+import os as _os
+_OVERLAP_FWD = _os.environ.get("VJ_OVERLAP_FWD", "1") != "0"   # diagnostics: 0 = target forward on the main stream
+
+
 def _strip(name):
     return name[len("backbone."):] if name.startswith("backbone.") else name
 
@@ -219,7 +223,8 @@ class Trainer:
             Bc = c1 - c0
             # ---- forward: the EMA target branch is independent of the context branch until the loss, so it runs on
             #      the side stream concurrently (fills the tails of each other's kernels)
-            if side.enabled:
+            fwd_overlap = side.enabled and _OVERLAP_FWD
+            if fwd_overlap:
                 side.fork(cl, *mp)
                 with torch.cuda.stream(side.stream):
                     h = self.forward_target(cl, mp)
@@ -228,7 +233,7 @@ class Trainer:
             z, segs, saved_e = encoder_forward(self.ew, cl, me, save=True, ws_tag="enc_save")
             zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, me, mp, save=True, ws_tag="pred_save")
             mark('context+predictor forward (main stream)')
-            if side.enabled:
+            if fwd_overlap:
                 side.join()
                 for t in h:
                     t.record_stream(torch.cuda.current_stream())

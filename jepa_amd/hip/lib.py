@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (loads torch/lib/libamdhip64.so before our DT_NEEDED is resolved)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvjepa_hip.so")
+_VARIANT = os.environ.get("VJ_LIB_VARIANT", "")   # A/B builds for kernel experiments (python -m jepa_amd.build <variant> ...)
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", f"libvjepa_hip_{_VARIANT}.so" if _VARIANT else "libvjepa_hip.so")
 
 P = ctypes.c_void_p
 I64 = ctypes.c_int64

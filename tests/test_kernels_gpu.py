@@ -150,7 +150,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, 1, 0x20, 0x80, 0xC0])   # auto | reg-staged | 256x256 | BK32 ring | 8-phase
+@pytest.mark.parametrize("flags", [0, 1, 0x20, 0x80, 0xC0, 0x100])   # auto | reg-staged | 256x256 | BK32 ring | 8-phase | 4-wave 2 WG/CU
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_plain_bias_residual(ops, flags, M, N, K):
     g = torch.Generator().manual_seed(6)
@@ -405,3 +405,43 @@ def test_gemm_wgrad_splitk_and_fused_colsum(ops, M, N, K):
     out2 = torch.full((M, N), 1.0, device=DEV)
     ops.gemm_wgrad(dYt, Xt, out2, alpha=0.25, beta=3.0)
     assert torch.equal(out, out2)  # deterministic
+
+
+# ------------------------------------------------------------------------------------------ 4-wave GEMM (gemm4w.hip)
+@pytest.mark.parametrize("M,N,K", [(512, 256, 128), (1000, 384, 384), (2311, 1152, 384), (4099, 1024, 1024),
+                                   (256, 128, 64), (300, 200, 192), (37632, 1024, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_4wave_two_workgroups_per_cu_matches_8phase_bitwise(ops, M, N, K, epi):
+    """The 256x128 / 4-wave / two-workgroups-per-CU kernel accumulates every output element over the same K-tile and
+    k-step order as the 256x256 8-phase kernel and shares its epilogues: results must be BIT-identical (any DMA / LDS
+    race of the new schedule shows up as a mismatch), for every epilogue, interior and edge tiles, K from one to 16
+    K-tiles; repeated to catch timing-dependent races."""
+    g = torch.Generator().manual_seed(77)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = bf(torch.randn(M, N, generator=g)).to(DEV)
+    aux = bf(torch.randn(M, N, generator=g)).to(DEV)
+
+    def run(flags):
+        if epi == 0:
+            return ops.gemm_nt(A, W, bias=bias, residual=res, flags=flags), None
+        if epi == 1:
+            u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            return ops.gemm_nt(A, W, bias=bias, aux_out=u, epilogue=ops.EPI_GELU, flags=flags), u
+        if epi == 2:
+            return ops.gemm_nt(A, W, aux_in=aux, epilogue=ops.EPI_DGELU, flags=flags), None
+        out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        lib = ops.load_library()
+        ops.check(lib.vj_gemm_bf16_nt(A.data_ptr(), K, W.data_ptr(), K, out.data_ptr(), N, M, N, K, None, None, 0, None,
+                                      None, 0, 3, 0.5, 0.0, flags, torch.cuda.current_stream().cuda_stream), "gemm f32")
+        return out, None
+    ref, ref_u = run(0xC0)         # 8-phase 256x256
+    for _ in range(3):
+        out, u = run(0x100)
+        assert torch.equal(out, ref), float((out.float() - ref.float()).abs().max())
+        if ref_u is not None:
+            assert torch.equal(u, ref_u)
+    if epi == 0:   # and against fp32 torch, like every other GEMM test
+        r = A.float() @ W.float().t() + bias + res.float()
+        assert rel_l2(out, r) < 4e-3

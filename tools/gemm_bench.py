@@ -31,7 +31,7 @@ def main():
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
-    cfgs = [tuple(int(v) for v in c.split(".")) for c in args.cfgs.split(",")]
+    cfgs = [tuple(int(v) for v in c.split(".")) for c in args.cfgs.split(",")]   # "4.0" = flags 0x100 (gemm4w.hip)
     print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " + " ".join(f"t{c}p{q}(TF/s)" for c, q in cfgs))
     for tag, M, N, K, epi in SHAPES:
         A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
@@ -41,7 +41,7 @@ def main():
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
         res = []
         for c, q in cfgs:
-            flags = (c << 4) | (q << 6)
+            flags = 0x100 if c == 4 else (c << 4) | (q << 6)
 
             def run():
                 if epi == 3:
