@@ -2,7 +2,7 @@
  * vjepa_hip.h -- C ABI of libvjepa_hip.so: the MI355X (gfx950 / CDNA4) kernels of the V-JEPA pretraining step.
  *
  * The reference (facebookresearch/jepa) has no FFI layer: its device work is the ATen operator stream issued by
- * app/vjepa/train.py:414-498 through src/models/*.  This header is the boundary a maintainer would bind instead of
+ * app/vjepa/train.py:414-498 through the modules of src/models.  This header is the boundary a maintainer would bind instead of
  * those ATen calls (see INTEGRATION.md for the ctypes stub).  Each entry point names the reference call site it
  * replaces.  Conventions:
  *   - every function returns 0 on success, a negative value for an argument error, or a positive hipError_t;
@@ -235,6 +235,23 @@ int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, 
  * 2 attention backward): ms[3], flop[3], launches[3]; csv_path (nullable) receives one line per launch. */
 int vj_prof_enable(int on);
 int vj_prof_collect(double* ms, double* flop, int64_t* launches, const char* csv_path);
+
+/* ---- gradient collective over RCCL / xGMI -------------------------------------------------------------------
+ * DistributedDataParallel's gradient averaging (app/vjepa/train.py:295-297; src/utils/distributed.py:18-47) for hosts
+ * without torch.distributed: one process per GPU, SUM all-reduce of slices ("buckets") of the flat fp32 gradient arena
+ * on a communication stream the caller orders against the backward with events (the mean is folded into the fused
+ * AdamW kernel's gscale = 1/world, see vj_adamw_ema_guarded).  librccl.so is dlopen()ed on first use (the copy already
+ * mapped by the process, e.g. PyTorch's, is reused).  Rank 0 calls vj_comm_unique_id and ships the
+ * vj_comm_unique_id_bytes() = 128 bytes to the other ranks out of band; every rank then calls vj_comm_init on its own
+ * current HIP device.  The Python engine (jepa_amd/engine/dp.py) keeps using torch.distributed's RCCL backend by
+ * default -- same library, same collectives -- so that it shares the launcher's process group. */
+typedef struct vj_comm_opaque* vj_comm_t;
+int64_t vj_comm_unique_id_bytes(void);
+int vj_comm_unique_id(void* id_out);
+int vj_comm_init(vj_comm_t* comm_out, int rank, int world, const void* id);
+int vj_comm_allreduce_bucket(vj_comm_t comm, float* grad, int64_t count, vj_stream_t stream);   /* in place, SUM */
+int vj_comm_broadcast(vj_comm_t comm, float* buf, int64_t count, int root, vj_stream_t stream);  /* parameter sync */
+int vj_comm_destroy(vj_comm_t comm);
 
 /* ---- hardware probes (tests / profiles only) ---------------------------------------------------------------- */
 int vj_probe_tr16(uint32_t* out256, int addr_scale, vj_stream_t stream);

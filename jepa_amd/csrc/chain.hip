@@ -259,7 +259,7 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
 #define WGRAD_WS_BYTES ((int64_t)96 << 20)
 
 struct BwdLayout {
-  int64_t du[2], dx1[2], dqkv[2], dx[3], dy2, dob, dy1, delta, ln_ws, dyT, xT, tcs_ws, wg_ws, total;
+  int64_t du[2], dx1[2], dqkv[2], dx[3], dy2, dob, dy1, delta, ln_ws, dyT[2], xT[2], tcs_ws[2], wg_ws[2], total;
   int64_t ln_ws_bytes, tcs_ws_bytes, delta_bytes;
 };
 static BwdLayout bwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
@@ -284,12 +284,14 @@ static BwdLayout bwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
   L.delta = take(L.delta_bytes);
   L.ln_ws_bytes = vj_layernorm_bwd_ws_bytes(D);
   L.ln_ws = take(L.ln_ws_bytes);
-  L.dyT = take(nmax * Mp * 2);
-  L.xT = take(Dh * Mp * 2);
   L.tcs_ws_bytes = vj_transpose_colsum_ws_bytes(M, nmax);
   if (vj_colsum_ws_bytes(nmax) > L.tcs_ws_bytes) L.tcs_ws_bytes = vj_colsum_ws_bytes(nmax);
-  L.tcs_ws = take(L.tcs_ws_bytes);
-  L.wg_ws = take(WGRAD_WS_BYTES);
+  for (int w = 0; w < 2; w++) {   // one set per weight-gradient lane (see SideCtx)
+    L.dyT[w] = take(nmax * Mp * 2);
+    L.xT[w] = take(Dh * Mp * 2);
+    L.tcs_ws[w] = take(L.tcs_ws_bytes);
+    L.wg_ws[w] = take(WGRAD_WS_BYTES);
+  }
   L.total = off;
   return L;
 }
@@ -298,8 +300,23 @@ extern "C" int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int6
   return bwd_layout(M, D, Dh, heads).total;
 }
 
+// A second, library-owned lane for the weight gradients (VJ_WGRAD_LANES=2): fc2 / proj go to the caller's side stream,
+// fc1 / qkv to the lane; each lane is a dependent chain of small kernels (transpose, transpose, GEMM, slice reduction,
+// bias reduction), two of them fill each other's launch gaps.  The lane is joined into `side` at the end of every block,
+// so the caller still sees ONE producer stream.
+static hipStream_t g_lane2 = nullptr;
+static int g_lanes = [] { const char* e = getenv("VJ_WGRAD_LANES"); return e ? atoi(e) : 1; }();
+static hipStream_t lane2() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (hipStreamCreateWithFlags(&g_lane2, hipStreamNonBlocking) != hipSuccess) g_lane2 = nullptr;
+  });
+  return g_lane2;
+}
+
 struct SideCtx {
   hipStream_t main, side;   // side == main: serial mode
+  hipStream_t side2;        // second weight-gradient lane or nullptr
   char* tmp;
   const BwdLayout* L;
   int64_t M;
@@ -308,24 +325,25 @@ struct SideCtx {
 };
 
 // dW (fp32, += beta*old) = alpha * dy^T x_in ; db = alpha * colsum(dy) -- on the side stream, after `main` produced dy
-static int wgrad(const SideCtx& c, const void* dy, const void* x_in, const vj_linear_t& lw) {
+static int wgrad(const SideCtx& c, const void* dy, const void* x_in, const vj_linear_t& lw, int lane = 0) {
   const int64_t M = c.M, Mp = pad64i(M), N = lw.n_out, K = lw.k_in;
-  if (c.side != c.main) CH(stream_after(c.side, c.main, "vj_blocks_bwd(fork)"));
-  hipStream_t st = c.side;
+  if (lane == 1 && c.side2 == nullptr) lane = 0;
+  hipStream_t st = lane == 1 ? c.side2 : c.side;
+  if (st != c.main) CH(stream_after(st, c.main, "vj_blocks_bwd(fork)"));
   if (c.tn && N % 8 == 0 && K % 8 == 0) {
-    if (lw.gb) CH(vj_colsum_bf16(dy, M, N, N, M > 0 ? M : 1, 0, M > 0 ? M : 1, lw.gb, c.alpha, c.beta, c.tmp + c.L->tcs_ws,
+    if (lw.gb) CH(vj_colsum_bf16(dy, M, N, N, M > 0 ? M : 1, 0, M > 0 ? M : 1, lw.gb, c.alpha, c.beta, c.tmp + c.L->tcs_ws[lane],
                                  c.L->tcs_ws_bytes, st));
     ProfScope ps(st, 0, 2.0 * M * N * K, N, K, M, 3);
-    return vj_gemm_bf16_tn_splitk(dy, N, x_in, K, lw.gw, K, M, N, K, c.alpha, c.beta, c.tmp + c.L->wg_ws, WGRAD_WS_BYTES, st);
+    return vj_gemm_bf16_tn_splitk(dy, N, x_in, K, lw.gw, K, M, N, K, c.alpha, c.beta, c.tmp + c.L->wg_ws[lane], WGRAD_WS_BYTES, st);
   }
-  char* dyT = c.tmp + c.L->dyT;
-  char* xT = c.tmp + c.L->xT;
-  if (lw.gb) CH(vj_transpose_colsum_bf16(dy, dyT, M, N, N, Mp, lw.gb, c.alpha, c.beta, c.tmp + c.L->tcs_ws,
+  char* dyT = c.tmp + c.L->dyT[lane];
+  char* xT = c.tmp + c.L->xT[lane];
+  if (lw.gb) CH(vj_transpose_colsum_bf16(dy, dyT, M, N, N, Mp, lw.gb, c.alpha, c.beta, c.tmp + c.L->tcs_ws[lane],
                                          c.L->tcs_ws_bytes, st));
   else CH(vj_transpose_bf16(dy, dyT, M, N, N, Mp, st));
   CH(vj_transpose_bf16(x_in, xT, M, K, K, Mp, st));
   ProfScope ps(st, 0, 2.0 * N * K * Mp, N, K, Mp, 3);
-  return vj_gemm_bf16_nt_splitk(dyT, Mp, xT, Mp, lw.gw, K, N, K, Mp, c.alpha, c.beta, 0, c.tmp + c.L->wg_ws,
+  return vj_gemm_bf16_nt_splitk(dyT, Mp, xT, Mp, lw.gw, K, N, K, Mp, c.alpha, c.beta, 0, c.tmp + c.L->wg_ws[lane],
                                 WGRAD_WS_BYTES, st);
 }
 
@@ -354,7 +372,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
   }
   const char* sv = (const char*)save_ws;
   char* tmp = (char*)tmp_ws;
-  SideCtx sc{stream, side ? side : stream, tmp, &L, M, alpha, beta_acc, flags & 1};
+  SideCtx sc{stream, side ? side : stream, (side && g_lanes >= 2) ? lane2() : nullptr, tmp, &L, M, alpha, beta_acc, flags & 1};
   constexpr int MAX_BLOCKS = 256;
   VJ_CHECK_ARG(n_blocks <= MAX_BLOCKS, "vj_blocks_bwd: more than %d blocks", MAX_BLOCKS);
   hipEvent_t side_done[MAX_BLOCKS];
@@ -374,7 +392,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     CH(wgrad(sc, dx2, w + F.g, b.fc2));
     CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream, g_dgrad_flags));
     // fc1
-    CH(wgrad(sc, du, w + F.y2, b.fc1));
+    CH(wgrad(sc, du, w + F.y2, b.fc1, 1));
     CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     CH(vj_layernorm_bwd(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
                         dx1, b.norm2.gg, b.norm2.gb, alpha, beta_acc, M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
@@ -390,11 +408,12 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
                      tmp + L.delta, L.delta_bytes, stream));
     }
     // qkv
-    CH(wgrad(sc, dqkv, w + F.y1, b.qkv));
+    CH(wgrad(sc, dqkv, w + F.y1, b.qkv, 1));
     CH(gemm(dqkv, 3 * D, b.qkv.wT, b.qkv.ldwT, tmp + L.dy1, D, M, D, 3 * D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0,
             stream, g_dgrad_flags));
     CH(vj_layernorm_bwd(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
                         b.norm1.gg, b.norm1.gb, alpha, beta_acc, M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    if (sc.side2) CH(stream_after(sc.side, sc.side2, "vj_blocks_bwd(lane join)"));
     if (sc.side != sc.main) {
       hipEvent_t e = next_event();
       HIPCH(hipEventRecord(e, sc.side), "vj_blocks_bwd");

@@ -92,6 +92,12 @@ SIGNATURES = {
                             P, I64, P, I64, I32, P, P, LAYER_CB, P]),
     "vj_prof_enable": (I32, [I32]),
     "vj_prof_collect": (I32, [F64P, F64P, I64P, ctypes.c_char_p]),
+    "vj_comm_unique_id_bytes": (I64, []),
+    "vj_comm_unique_id": (I32, [P]),
+    "vj_comm_init": (I32, [ctypes.POINTER(P), I32, I32, P]),
+    "vj_comm_allreduce_bucket": (I32, [P, P, I64, P]),
+    "vj_comm_broadcast": (I32, [P, P, I64, I32, P]),
+    "vj_comm_destroy": (I32, [P]),
     "vj_probe_tr16": (I32, [P, I32, P]),
     "vj_probe_copy": (I32, [P, P, I64, P]),
 }

@@ -289,6 +289,29 @@ def test_two_rank_step_on_one_gpu_matches_oracle_with_averaged_gradients():
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
 
 
+def test_vj_comm_c_abi_single_rank_roundtrip():
+    """vj_comm_* (RCCL behind the C ABI, librccl dlopen()ed): unique id -> communicator of one rank on cuda:0 -> in-place
+    SUM all-reduce and broadcast leave the data bit-identical -> destroy.  (Multi-rank runs need more than one GPU.)"""
+    import ctypes
+    from jepa_amd.hip.lib import check, load_library
+    lib = load_library()
+    n = lib.vj_comm_unique_id_bytes()
+    assert n == 128
+    uid = (ctypes.c_ubyte * n)()
+    check(lib.vj_comm_unique_id(uid), "vj_comm_unique_id")
+    comm = ctypes.c_void_p()
+    check(lib.vj_comm_init(ctypes.byref(comm), 0, 1, uid), "vj_comm_init")
+    g = torch.randn(1 << 20, device=DEV)
+    ref = g.clone()
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.vj_comm_allreduce_bucket(comm, g.data_ptr(), g.numel(), st), "vj_comm_allreduce_bucket")
+    check(lib.vj_comm_broadcast(comm, g.data_ptr(), g.numel(), 0, st), "vj_comm_broadcast")
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    check(lib.vj_comm_destroy(comm), "vj_comm_destroy")
+    assert lib.vj_comm_init(ctypes.byref(comm), 3, 2, uid) < 0      # rank outside the world: rejected before RCCL
+
+
 # ------------------------------------------------------------------------------------------------ module forwards
 def test_standalone_block_forwards_match_torch():
     """MLP / Attention / Block / PatchEmbed3D.forward (inference, no grad) vs the same arithmetic in fp32 torch:

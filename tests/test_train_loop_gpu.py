@@ -55,9 +55,12 @@ def test_main_trains_logs_checkpoints_and_resumes(tmp_path):
     assert 'module.backbone.blocks.0.attn.qkv.weight' in ck['encoder']
     assert 'module.backbone.predictor_blocks.1.mlp.fc2.bias' in ck['predictor']
     assert 'module.backbone.pos_embed' in ck['target_encoder']
-    n_params = sum(1 for _ in ck['opt']['state'])
-    assert n_params == len(ck['opt']['param_groups'][0]['params']) + len(ck['opt']['param_groups'][1]['params']) + \
-        len(ck['opt']['param_groups'][2]['params']) + len(ck['opt']['param_groups'][3]['params'])
+    # like torch.optim.AdamW built by the reference's init_opt: the two frozen sincos tables (pos_embed, predictor_pos_embed)
+    # are members of groups 0 / 1 and consume a parameter id, but carry no state
+    n_state = sum(1 for _ in ck['opt']['state'])
+    n_members = sum(len(g['params']) for g in ck['opt']['param_groups'])
+    assert n_state == n_members - 2
+    assert sorted(i for g in ck['opt']['param_groups'] for i in g['params']) == list(range(n_members))
     # EMA moved the target away from its initial copy but keeps it close to the encoder
     e = ck['encoder']['module.backbone.blocks.0.attn.qkv.weight']
     t = ck['target_encoder']['module.backbone.blocks.0.attn.qkv.weight']
