@@ -213,9 +213,11 @@ typedef void (*vj_layer_cb_t)(void* user, int layer);
 /* save != 0: every block keeps what its backward needs (16*D bf16 per token: x, LN1 out, qkv, o, x1, LN2 out,
  * pre-GELU u, GELU out + row statistics + softmax lse) in `ws`; save == 0: one such set is reused by all blocks. */
 int64_t vj_blocks_fwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads, int64_t n_blocks, int save);
-/* x_out [M,D] bf16 = blocks[n-1](...blocks[0](x_in)) ; x_in must stay valid until the backward has run. */
+/* x_out [M,D] bf16 = blocks[n-1](...blocks[0](x_in)) ; x_in must stay valid until the backward has run.
+ * gemm_flags: kernel selection for the four Linear GEMMs of every block, as in vj_gemm_bf16_nt (0 = automatic;
+ * 0x100 = the two-workgroups-per-CU kernel, the better choice when this stream has the GPU to itself: inference). */
 int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M, int64_t D,
-                  int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save, void* ws,
+                  int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save, int gemm_flags, void* ws,
                   int64_t ws_bytes, vj_stream_t stream);
 int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads);
 /* dx_out [M,D] bf16 = d loss / d x_in given dout = d loss / d x_out; parameter gradients are written as

@@ -209,7 +209,8 @@ static int check_segs(const vj_seg_t* segs, int64_t n_segs, int64_t M, const cha
 // ---------------------------------------------------------------------------------------------------- forward
 extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M,
                              int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save,
-                             void* ws, int64_t ws_bytes, hipStream_t stream) {
+                             int gemm_flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  const int fwd_flags = gemm_flags ? gemm_flags : g_fwd_flags;
   CH(check_blocks(blocks, n_blocks, D, "vj_blocks_fwd"));
   CH(check_segs(segs, n_segs, M, "vj_blocks_fwd"));
   VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_fwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
@@ -236,7 +237,7 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
     float* mean2 = save ? (float*)(w + L.mean2) : nullptr;
     float* rstd2 = save ? (float*)(w + L.rstd2) : nullptr;
     CH(vj_layernorm_fwd(x, b.norm1.g, b.norm1.b, w + L.y1, mean1, rstd1, M, D, ln_eps, stream));
-    CH(gemm(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_fwd_flags));
+    CH(gemm(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 0, stream, fwd_flags));
     for (int64_t s = 0; s < n_segs; s++) {
       const vj_seg_t& sg = segs[s];
       if (sg.B * sg.S == 0) continue;
@@ -245,11 +246,11 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
       CH(vj_attn_fwd(w + L.qkv + sg.row0 * 3 * D * 2, w + L.o + sg.row0 * D * 2, lse, sg.B, sg.S, heads, hd, scale,
                      stream));
     }
-    CH(gemm(w + L.o, D, b.proj.w, D, w + L.x1, D, M, D, D, b.proj.b, x, D, nullptr, nullptr, 0, 0, stream, g_fwd_flags));
+    CH(gemm(w + L.o, D, b.proj.w, D, w + L.x1, D, M, D, D, b.proj.b, x, D, nullptr, nullptr, 0, 0, stream, fwd_flags));
     CH(vj_layernorm_fwd(w + L.x1, b.norm2.g, b.norm2.b, w + L.y2, mean2, rstd2, M, D, ln_eps, stream));
     CH(gemm(w + L.y2, D, b.fc1.w, D, w + L.g, Dh, M, Dh, D, b.fc1.b, nullptr, 0, nullptr, save ? w + L.u : nullptr, Dh,
-            1, stream, g_fwd_flags));
-    CH(gemm(w + L.g, Dh, b.fc2.w, Dh, x2, D, M, D, Dh, b.fc2.b, w + L.x1, D, nullptr, nullptr, 0, 0, stream, g_fwd_flags));
+            1, stream, fwd_flags));
+    CH(gemm(w + L.g, Dh, b.fc2.w, Dh, x2, D, M, D, Dh, b.fc2.b, w + L.x1, D, nullptr, nullptr, 0, 0, stream, fwd_flags));
     x = x2;
   }
   return 0;

@@ -83,7 +83,7 @@ def _blocks_of(views):
     return arr
 
 
-def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None):
+def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None, gemm_flags=0):
     """x [M, D] bf16 -> (x_out [M, D] bf16, TrunkCtx or None).  `views`: EncoderW / PredictorW (`.blocks`, `.heads`)."""
     lib = load_library()
     M, D = x.shape
@@ -96,7 +96,7 @@ def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None):
     sa = seg_array(segs)
     st = torch.cuda.current_stream().cuda_stream if stream is None else stream
     check(lib.vj_blocks_fwd(arr, n, x.data_ptr(), out.data_ptr(), M, D, views.heads, sa, len(segs), ln_eps, int(save),
-                            ws.data_ptr(), ws.numel(), st), "vj_blocks_fwd")
+                            gemm_flags, ws.data_ptr(), ws.numel(), st), "vj_blocks_fwd")
     return out, (TrunkCtx(x, ws, M, D, segs, sa) if save else None)
 
 

@@ -40,11 +40,15 @@ class HipModule:
             raise ValueError("move the module to the GPU first (.to('cuda')): jepa_amd has no CPU compute path")
         first = params[0][1]
         if st is None or st["arena"].device != dev or st["ptr"] != first.data_ptr():
-            trainable = [(n, p) for n, p in params if p.requires_grad]
-            arena = ParamArena([trainable], dev, with_moments=False, bind_grads=False)
-            arena.frozen = {n: p.data.to(torch.float32).contiguous() for n, p in params if not p.requires_grad}
+            # weights live in the arena whether or not they require grad (a frozen encoder under eval is the normal
+            # inference case, evals/video_classification_frozen/eval.py:414-441); only the sincos position tables --
+            # never GEMM operands -- stay outside as fp32 tensors
+            tables = ("pos_embed", "predictor_pos_embed")
+            weights = [(n, p) for n, p in params if n.split(".")[-1] not in tables]
+            arena = ParamArena([weights], dev, with_moments=False, bind_grads=False)
+            arena.frozen = {n: p.data.to(torch.float32).contiguous() for n, p in params if n.split(".")[-1] in tables}
             st = {"arena": arena, "ptr": first.data_ptr(), "version": None, "has_T": False,
-                  "names": [n for n, _ in trainable]}
+                  "names": [n for n, _ in weights]}
             self.__dict__["_hip_private"] = st
         arena = st["arena"]
         version = sum(p._version for _, p in params)

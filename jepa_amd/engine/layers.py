@@ -167,7 +167,8 @@ def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: f
 
 
 # =============================================================================================== encoder
-def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], save: bool, final_norm=True, ws_tag=None):
+def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], save: bool, final_norm=True, ws_tag=None,
+                    gemm_flags=0):
     """clips fp32 [B,3,T,H,W]; masks: None (all N tokens) or a list of int64 [B,K_i] index tensors.
     Returns (out [sum_i B*K_i, D] bf16, segs, saved).  With final_norm=False the last residual stream is returned
     (the target path fuses the final norm into vj_target_rows)."""
@@ -186,11 +187,11 @@ def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], sa
         tok = torch.empty((r, kdim), dtype=torch.bfloat16, device=clips.device)
         for sg, m in zip(segs, masks):
             ops.tubelet_pack(clips, ew.tubelet, ew.patch_size, idx=m, out=_rows(tok, sg))
-    x = ops.gemm_nt(tok, ew.patch.w, bias=ew.patch.b)
+    x = ops.gemm_nt(tok, ew.patch.w, bias=ew.patch.b, flags=gemm_flags or None)
     for i, sg in enumerate(segs):
         ops.add_pos(_rows(x, sg), ew.pos, sg.B, sg.S, idx=None if masks is None else masks[i])
     if ws_tag is not None and USE_C_CHAIN:    # ws_tag: the caller owns one workspace per trunk (engine/chain.py)
-        x, saved_blocks = chain.blocks_forward(x, ew, segs, save, ws_tag, LN_EPS)
+        x, saved_blocks = chain.blocks_forward(x, ew, segs, save, ws_tag, LN_EPS, gemm_flags=gemm_flags)
     else:
         saved_blocks = []
         for bw in ew.blocks:
@@ -226,7 +227,8 @@ def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_don
 
 
 # =============================================================================================== predictor
-def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_pred, save: bool, ws_tag=None):
+def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_pred, save: bool, ws_tag=None,
+                      gemm_flags=0):
     """z [sum_i B*Ke_i, D] bf16 (context-encoder output rows, per-mask segments enc_segs).
     Returns (zhat [sum_i B*Kp_i, D] bf16, tgt_segs, saved)."""
     Dp = pw.embed.w.shape[0]
@@ -246,7 +248,7 @@ def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_p
         ops.pred_assemble(_rows(e, sg), pw.mask_tokens[i % n_tok], pw.pos, masks_enc[i], masks_pred[i],
                           out=_rows(x, psg))
     if ws_tag is not None and USE_C_CHAIN:
-        x, saved_blocks = chain.blocks_forward(x, pw, segs, save, ws_tag, LN_EPS)
+        x, saved_blocks = chain.blocks_forward(x, pw, segs, save, ws_tag, LN_EPS, gemm_flags=gemm_flags)
     else:
         saved_blocks = []
         for bw in pw.blocks:

@@ -85,8 +85,8 @@ SIGNATURES = {
     "vj_sqnorm_ws_bytes": (I64, []),
     "vj_sqnorm_f32": (I32, [P, I64, P, I32, P, I64, P]),
     "vj_blocks_fwd_ws_bytes": (I64, [I64, I64, I64, I64, I64, I32]),
-    "vj_blocks_fwd": (I32, [ctypes.POINTER(VjBlock), I64, P, P, I64, I64, I64, ctypes.POINTER(VjSeg), I64, F32, I32, P,
-                            I64, P]),
+    "vj_blocks_fwd": (I32, [ctypes.POINTER(VjBlock), I64, P, P, I64, I64, I64, ctypes.POINTER(VjSeg), I64, F32, I32, I32,
+                            P, I64, P]),
     "vj_blocks_bwd_ws_bytes": (I64, [I64, I64, I64, I64]),
     "vj_blocks_bwd": (I32, [ctypes.POINTER(VjBlock), I64, P, P, P, I64, I64, I64, ctypes.POINTER(VjSeg), I64, F32, F32,
                             P, I64, P, I64, I32, P, P, LAYER_CB, P]),

@@ -95,8 +95,14 @@ class VisionTransformer(nn.Module, hipmodule.HipModule):
     def _hip_views(self, train):
         from ...engine.weights import encoder_views
         arena, prefix = self._hip_arena(train)
-        return encoder_views(arena, prefix, self, arena.frozen[prefix + "pos_embed"].reshape(self.num_patches, -1),
-                             train)
+        cache = self.__dict__.setdefault("_hip_view_cache", {})
+        key = (id(arena), prefix, bool(train), len(arena.wT))
+        v = cache.get(key)
+        if v is None:   # the views (and the C descriptor array hanging off them) only change with the arena
+            cache.clear()
+            v = cache[key] = encoder_views(arena, prefix, self,
+                                           arena.frozen[prefix + "pos_embed"].reshape(self.num_patches, -1), train)
+        return v
 
     def forward_masks(self, x, masks):
         """All masks through one fused chain; returns a list with one [B, K_i, D] tensor per mask."""
@@ -122,9 +128,17 @@ class VisionTransformer(nn.Module, hipmodule.HipModule):
             masks = [m.contiguous() for m in masks]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return hipmodule.run_with_autograd(self, _enc_fwd, _enc_bwd, (x, masks))
+        # inference: one C call per trunk (no saved activations, a private workspace) and, because nothing else shares the
+        # GPU with this stream, the two-workgroups-per-CU GEMM (gemm4w.hip; see DESIGN.md section 6 for why training does not)
         ew = self._hip_views(train=False)
-        out, segs, _ = encoder_forward(ew, x, masks, save=False)
+        # (ViT-L B=24 forward: 728.7 -> 761.1 clips/s; ViT-H, whose 1280 = 5 x 256 columns tile the big kernel exactly: 405.6 vs
+        # 395.9, so the wide models keep the automatic selection -- tools/infer_bench.py)
+        flags = INFER_GEMM_FLAGS if self.embed_dim <= 1024 else 0
+        out, segs, _ = encoder_forward(ew, x, masks, save=False, ws_tag=f"infer{id(self)}", gemm_flags=flags)
         return out, segs
+
+
+INFER_GEMM_FLAGS = 0x100
 
 
 def _enc_fwd(module, ew, args, diff):

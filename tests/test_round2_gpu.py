@@ -352,3 +352,105 @@ def test_standalone_block_forwards_match_torch():
     with pytest.raises(ValueError):
         with torch.no_grad():
             blk.cpu()(x.cpu())                            # and there is no CPU path
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def test_chain_rejects_bad_arguments_before_launching():
+    """vj_blocks_fwd / vj_blocks_bwd validate on the host: too-small or misaligned workspaces, segments that do not tile
+    the rows, inconsistent Linear shapes -> negative return code + vj_last_error(), nothing enqueued."""
+    import ctypes
+    from jepa_amd.engine import chain
+    from jepa_amd.engine.layers import Seg
+    from jepa_amd.hip.lib import load_library
+    lib = load_library()
+    tr, _, _, _, _ = build_trainer(TINY, 2)
+    ew = tr.ew
+    M, D = 96, 192
+    x = torch.randn(M, D, device=DEV).bfloat16()
+    out = torch.empty_like(x)
+    arr = chain.block_array(ew.blocks)
+    n = len(ew.blocks)
+    st = torch.cuda.current_stream().cuda_stream
+    need = lib.vj_blocks_fwd_ws_bytes(M, D, 4 * D, ew.heads, n, 1)
+    ws = torch.empty(need + 512, dtype=torch.uint8, device=DEV)
+    good = chain.seg_array([Seg(0, 2, 48)])
+
+    def fwd(segs, nseg, ws_ptr, ws_bytes, heads=ew.heads):
+        return lib.vj_blocks_fwd(arr, n, x.data_ptr(), out.data_ptr(), M, D, heads, segs, nseg, 1e-6, 1, 0, ws_ptr, ws_bytes, st)
+    assert fwd(good, 1, ws.data_ptr(), ws.numel()) == 0
+    assert fwd(good, 1, ws.data_ptr(), need - 256) < 0 and b"workspace too small" in lib.vj_last_error()
+    assert fwd(good, 1, ws.data_ptr() + 64, ws.numel() - 64) < 0 and b"aligned" in lib.vj_last_error()
+    assert fwd(chain.seg_array([Seg(0, 2, 40)]), 1, ws.data_ptr(), ws.numel()) < 0 and b"segments" in lib.vj_last_error()
+    assert fwd(chain.seg_array([Seg(8, 2, 44)]), 1, ws.data_ptr(), ws.numel()) < 0
+    assert fwd(good, 1, ws.data_ptr(), ws.numel(), heads=5) < 0 and b"divisible" in lib.vj_last_error()
+    # backward without transposed weights / gradient views (a forward-only descriptor) is refused
+    tw_arr = chain.block_array(tr.tw.blocks)
+    nb = lib.vj_blocks_bwd_ws_bytes(M, D, 4 * D, ew.heads)
+    tmp = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    rc = lib.vj_blocks_bwd(tw_arr, n, x.data_ptr(), out.data_ptr(), out.data_ptr(), M, D, ew.heads, good, 1, 1.0, 0.0,
+                           ws.data_ptr(), ws.numel(), tmp.data_ptr(), tmp.numel(), 0, st, None, chain.LAYER_CB(), None)
+    assert rc < 0 and b"lacks transposed weights" in lib.vj_last_error()
+    torch.cuda.synchronize()
+
+
+def test_micro_batches_with_the_variance_regulariser():
+    """reg_coeff != 0 couples the masks of one SAMPLE (pstd is summed over masks before the relu), never samples: the
+    micro-batched step must reproduce the full-batch loss_reg and gradients."""
+    clips, me, mp = draw_batch(_gens(), 4, TINY, 91, 92)
+    outs = []
+    for mb in (None, 2):
+        tr, _, _, pred, _ = build_trainer(TINY, 2, perturb_small=True, micro_batch=mb, reg_coeff=0.5)
+        with torch.no_grad():   # shrink the predictions so that relu(1 - pstd) is active
+            tr.arena.f32("pred.predictor_proj.weight").mul_(0.25)
+        tr.sync_shadows()
+        o = tr.train_step(*to_dev(clips, me, mp), lr=1e-3, wd=0.04, ema=0.99)
+        outs.append((o.loss, o.loss_reg, tr.arena.G.clone()))
+    assert outs[0][1] > 0.05, "test setup: the regulariser must be active"
+    assert abs(outs[1][0] - outs[0][0]) <= 2e-6 * abs(outs[0][0])
+    assert abs(outs[1][1] - outs[0][1]) <= 1e-5 * abs(outs[0][1])
+    assert rel_l2(outs[1][2].cpu(), outs[0][2].cpu()) < 1e-5
+
+
+def test_prefetcher_end_of_data_and_shape_changes():
+    """fetch() raising StopIteration ends the stream after the last batch is delivered; batches of changing mask widths
+    re-allocate their slot buffers."""
+    from jepa_amd.engine.input import DevicePrefetcher
+    host = [([torch.full((1, 3, 2, 8, 8), float(i))], [torch.arange(4 + i).view(1, -1)], [torch.arange(3).view(1, -1)])
+            for i in range(3)]
+    it = iter(host)
+    pf = DevicePrefetcher(lambda: next(it), torch.device(DEV))
+    for i in range(3):
+        c, me, mp = pf.next()
+        assert float(c.flatten()[0]) == float(i) and me[0].shape[1] == 4 + i
+    with pytest.raises(StopIteration):
+        pf.next()
+
+
+def test_frozen_encoder_inference_matches_oracle():
+    """The frozen-eval case (evals/video_classification_frozen/eval.py:414-441: every parameter requires_grad=False, called
+    under no_grad): one C launch chain per forward with the two-workgroups-per-CU GEMM.  Output vs the fp32 oracle on the
+    same weights: rel-L2 <= 2e-2; identical (bitwise) to the automatic GEMM selection."""
+    from oracle import vjepa_oracle as O
+    import jepa_amd.src.models.vision_transformer as V
+    enc, _ = build_models(TINY, 2, perturb_small=True)
+    vit = enc.backbone
+    w = {k: v.detach().clone() for k, v in vit.state_dict().items()}
+    for p in vit.parameters():
+        p.requires_grad = False
+    vit.to(DEV)
+    clips = torch.randn(3, 3, TINY["frames"], TINY["crop"], TINY["crop"], generator=torch.Generator().manual_seed(7))
+    ref = O.encoder_forward(w, clips, oracle_cfg(TINY, 2))
+    with torch.no_grad():
+        y = vit(clips.to(DEV))
+        assert rel_l2(y.float().cpu(), ref) < 2e-2
+        old = V.INFER_GEMM_FLAGS
+        try:
+            V.INFER_GEMM_FLAGS = 0
+            y0 = vit(clips.to(DEV))
+        finally:
+            V.INFER_GEMM_FLAGS = old
+        assert torch.equal(y, y0)
+        idx = torch.stack([torch.randperm(TINY["num_patches"])[:20].sort().values for _ in range(3)]).to(DEV)
+        ym = vit(clips.to(DEV), [idx])
+        refm = O.encoder_forward(w, clips, oracle_cfg(TINY, 2), idx.cpu())
+        assert rel_l2(ym.float().cpu(), refm) < 2e-2
