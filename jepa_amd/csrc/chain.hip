@@ -216,7 +216,7 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
   VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_fwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
   if (M == 0) return 0;
   const int64_t Dh = blocks[0].fc1.n_out, hd = D / heads;
-  const float scale = 1.0f / sqrtf((float)hd);
+  const float scale = (float)pow((double)hd, -0.5);   // head_dim ** -0.5 exactly as Attention.scale (modules.py:53) is computed on the host
   VJ_CHECK_ARG(ws != nullptr && ws_bytes >= vj_blocks_fwd_ws_bytes(M, D, Dh, heads, n_blocks, save),
                "vj_blocks_fwd: workspace too small (%ld < %ld)", (long)ws_bytes,
                (long)vj_blocks_fwd_ws_bytes(M, D, Dh, heads, n_blocks, save));
@@ -358,7 +358,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
   VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_bwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
   if (M == 0) return 0;
   const int64_t Dh = blocks[0].fc1.n_out, hd = D / heads;
-  const float scale = 1.0f / sqrtf((float)hd);
+  const float scale = (float)pow((double)hd, -0.5);   // head_dim ** -0.5 exactly as Attention.scale (modules.py:53) is computed on the host
   const FwdLayout F = fwd_layout(M, D, Dh, heads);
   const BwdLayout L = bwd_layout(M, D, Dh, heads);
   VJ_CHECK_ARG(save_ws != nullptr && save_ws_bytes >= F.total * n_blocks, "vj_blocks_bwd: saved-activation workspace too small");

@@ -128,3 +128,56 @@ def test_init_video_model_is_seed_for_seed_identical_to_reference():
             [n for n, p in ours.named_parameters() if p.requires_grad]
     for attr in ("embed_dim", "num_heads", "num_patches", "patch_size", "tubelet_size", "num_frames", "input_size"):
         assert getattr(re.backbone, attr) == getattr(oe.backbone, attr)
+
+
+@pytest.mark.reference
+def test_collators_match_the_live_reference_over_random_configs():
+    """40 random (config, seed, batch) draws of both collators against the reference's own classes imported from
+    /root/reference: index tensors bit-identical, including the shared step counter and max_keep / max_temporal_keep."""
+    import random
+    sys.path.insert(0, "/root/reference")
+    from src.masks.multiblock3d import MaskCollator as RefMB       # noqa: E402  (reference, read-only)
+    from src.masks.random_tube import MaskCollator as RefTube      # noqa: E402
+    from jepa_amd.src.masks.multiblock3d import MaskCollator as OurMB
+    from jepa_amd.src.masks.random_tube import MaskCollator as OurTube
+    rnd = random.Random(7)
+    for trial in range(40):
+        crop = rnd.choice([64, 128, 224, 384])
+        frames = rnd.choice([8, 16])
+        n_masks = rnd.choice([1, 2, 3])
+        cfgs = []
+        for _ in range(n_masks):
+            lo = rnd.choice([0.15, 0.2, 0.5, 0.7])
+            cfgs.append(dict(aspect_ratio=rnd.choice([(0.75, 1.5), (0.3, 3.0)]), num_blocks=rnd.choice([1, 2, 4, 8]),
+                             spatial_scale=(lo, rnd.choice([lo, min(0.9, lo + 0.2)])),
+                             temporal_scale=rnd.choice([(1.0, 1.0), (0.5, 1.0), (0.25, 0.75)]),
+                             max_temporal_keep=rnd.choice([1.0, 0.5]), max_keep=rnd.choice([None, None, 64])))
+        kw = dict(cfgs_mask=cfgs, crop_size=crop, num_frames=frames, patch_size=16, tubelet_size=2)
+        ours, ref = OurMB(**kw), RefMB(**kw)
+        B = rnd.choice([1, 2, 5, 24])
+        for it in range(3):
+            seed = rnd.randrange(1 << 30)
+            batch = [(torch.zeros(1), 0) for _ in range(B)]
+            torch.manual_seed(seed)
+            _, me_o, mp_o = ours(batch)
+            torch.manual_seed(seed)
+            _, me_r, mp_r = ref(batch)
+            for a, b in zip(me_o + mp_o, me_r + mp_r):
+                assert a.dtype == b.dtype and torch.equal(a, b), (trial, it)
+            if rnd.random() < 0.3:   # the resume path replays the counter (train.py:322-326)
+                ours.step()
+                ref.step()
+    for trial in range(10):
+        ratio = rnd.choice([0.5, 0.75, 0.9])
+        kw = dict(cfgs_mask=[dict(ratio=ratio)], crop_size=224, num_frames=16, patch_size=16, tubelet_size=2)
+        ours, ref = OurTube(**kw), RefTube(**kw)
+        seed = rnd.randrange(1 << 30)
+        batch = [(torch.zeros(1), 0) for _ in range(4)]
+        torch.manual_seed(seed)
+        np.random.seed(seed % (1 << 31))
+        _, me_o, mp_o = ours(batch)
+        torch.manual_seed(seed)
+        np.random.seed(seed % (1 << 31))
+        _, me_r, mp_r = ref(batch)
+        for a, b in zip(me_o + mp_o, me_r + mp_r):
+            assert torch.equal(a, b), ("tube", trial)

@@ -454,3 +454,45 @@ def test_frozen_encoder_inference_matches_oracle():
         ym = vit(clips.to(DEV), [idx])
         refm = O.encoder_forward(w, clips, oracle_cfg(TINY, 2), idx.cpu())
         assert rel_l2(ym.float().cpu(), refm) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE size
+@pytest.mark.timeout(600)
+def test_full_size_step_properties_vitl_b24():
+    """Size-independent properties at the benched configuration (ViT-L/16, 16x224x224, B=24, vitl16.yaml masks), where
+    the CPU oracle is too slow to run routinely: with lr = wd = 0 and ema = 1 a step leaves weights and target untouched,
+    so the SAME step can be repeated under different execution modes and must reproduce
+      * bit-identical losses and gradient arena: C launch chain vs per-kernel Python chain, and run-to-run (the split-K and
+        partial reductions are deterministic);
+      * the full-batch gradients from micro-batches of 12 and of 9 (uneven 9+9+6): rel-L2 <= 2e-5, loss <= 1e-6 relative;
+      * finite gradients everywhere, step not skipped, unchanged weights."""
+    from jepa_amd.engine import layers
+    from tests.step_util import VITL, VITL_MASKS
+    from oracle import vjepa_oracle as O
+    tr, _, _, _, _ = build_trainer(VITL, 2)
+    gens = O.make_mask_gens(VITL_MASKS, VITL["crop"], VITL["frames"], VITL["patch"], VITL["tubelet"])
+    clips, me, mp = draw_batch(gens, 24, VITL, 1234, 4321)
+    cd, med, mpd = to_dev(clips, me, mp)
+    P0, T0 = tr.arena.P.clone(), tr.tarena.P.clone()
+
+    def run(mb=None, c_chain=True):
+        tr.micro_batch = mb
+        layers.USE_C_CHAIN = c_chain
+        try:
+            o = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
+            return o.loss, tr.arena.G.clone(), o.skipped
+        finally:
+            layers.USE_C_CHAIN = True
+            tr.micro_batch = None
+    l0, g0, sk = run()
+    assert not sk and bool(torch.isfinite(g0).all()) and 0.1 < l0 < 5.0
+    l1, g1, _ = run()
+    assert l1 == l0 and torch.equal(g1, g0), "the step is not deterministic run-to-run"
+    lp, gp, _ = run(c_chain=False)
+    assert lp == l0 and torch.equal(gp, g0), "C launch chain and Python chain diverge at full size"
+    for mb in (12, 9):
+        lm, gm, _ = run(mb=mb)
+        assert abs(lm - l0) <= 1e-6 * abs(l0), (mb, lm, l0)
+        r = float((gm.double() - g0.double()).norm() / g0.double().norm())
+        assert r < 2e-5, (mb, r)
+    assert torch.equal(tr.arena.P, P0) and torch.equal(tr.tarena.P, T0)
