@@ -38,18 +38,51 @@ __device__ __forceinline__ void wait_vm() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// LDS-DMA through inline assembly (both addressing forms): the compiler then neither tracks these loads in its own
+// vmcnt bookkeeping nor assumes LDS was written, so the only waits in the K loop are the counted ones placed by hand.
+__device__ __forceinline__ unsigned lds_addr8(const char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void dma16_v(const void* gsrc, unsigned lds_dst) {   // 64-bit per-lane address
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(gsrc) : "memory");
+}
+__device__ __forceinline__ void dma16_sv(const char* sbase, unsigned voff, unsigned lds_dst) {   // SGPR base + 32-bit lane offset
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+
+// Interior tiles (all 256 x 256 rows exist): a part's two chunks per thread are rows r0 and r0 + 64 of the part at the
+// same swizzled chunk column, so their addresses are a WAVE-UNIFORM base per (operand, sub-part, j) -- fixed for the
+// whole K loop, held in SGPRs -- plus one 32-bit per-thread byte offset per operand (+ 128 bytes per K-tile).  That
+// removes the 64-bit VALU address arithmetic (v_mad_u64_u32 / v_lshl_add_u64 per chunk) from every load section.
+struct PartBase8 {
+  const char* a[2][2];   // [sub-part mq][j]: A rows m0 + j*128 + mq*64 (+ r0)
+  const char* b[2][2];   // [sub-part nq][j]: B rows n0 + j*128 + nq*32 (+ (r0>>5)*64 + (r0&31))
+  unsigned voff_a, voff_b;
+};
+
 // issue the LDS-DMA of part q (q = -1 .. 4*nk-1) into slot (q+8) % 8
-__device__ __forceinline__ void issue_part(const GemmArgs& p, int q, int64_t m0, int64_t n0, int kt0, char* smem,
-                                           int tid, int wave_u) {
+template <bool EDGE>
+__device__ __forceinline__ void issue_part(const GemmArgs& p, const PartBase8& pb, int q, int64_t m0, int64_t n0, int kt0,
+                                           char* smem, int tid, int wave_u) {
   // q = 4t+0 -> B0(t), 4t+1 -> B1(t), 4t+2 -> A1(t), 4t+3 -> A0(t+1);  q = -1 -> A0(0).  With qq = q + 1:
   // qq = 4T + kind, kind 0 = A0(T), 1 = B0(T), 2 = B1(T), 3 = A1(T)
   const int qq = q + 1;
   const int kind = qq & 3;
   const int t = qq >> 2;
-  const int64_t k0 = (int64_t)(kt0 + t) * P8_BK;
-  char* slot = smem + ((q + 8) & 7) * PART_BYTES;
+  const unsigned slot = lds_addr8(smem) + ((q + 8) & 7) * PART_BYTES;
   const bool isA = (kind == 0) || (kind == 3);
   const int sub = (kind == 0) ? 0 : (kind == 3 ? 1 : kind - 1);  // mq for A parts, nq for B parts
+  if constexpr (!EDGE) {
+    const unsigned koff = (unsigned)t * (P8_BK * 2);   // bytes along K
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const unsigned dst = slot + (j * 512 + wave_u * 64) * 16;
+      if (isA) dma16_sv(pb.a[sub][j], pb.voff_a + koff, dst);
+      else dma16_sv(pb.b[sub][j], pb.voff_b + koff, dst);
+    }
+    return;
+  }
+  const int64_t k0 = (int64_t)(kt0 + t) * P8_BK;
 #pragma unroll
   for (int j = 0; j < 2; j++) {
     const int c16 = j * 512 + tid;            // 16-byte chunk index inside the part (linear LDS image)
@@ -65,31 +98,42 @@ __device__ __forceinline__ void issue_part(const GemmArgs& p, int q, int64_t m0,
       gr = gr < p.N ? gr : p.N - 1;
       src = p.B + gr * p.ldb + k0 + c * 8;
     }
-    char* dst = slot + (j * 512 + wave_u * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    dma16_v(src, slot + (j * 512 + wave_u * 64) * 16);
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// One workgroup's tile.  EDGE: the tile sticks out of the matrix (per-chunk clamped 64-bit addressing); interior tiles use
+// the SGPR-base form.  Two instantiations of the same schedule; the kernel picks one per workgroup (uniform branch).
+template <int EPI, bool EDGE>
+__device__ __forceinline__ void gemm8_body(const GemmArgs& p, char* smem, int tm, int tn, int slice) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_u >> 2, wn = wave_u & 3;
   const bool late_group = wave_u >= 4;        // waves 4-7 run one barrier interval behind waves 0-3
   const int frow = lane & 15, fg = lane >> 4;
 
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int logical_all = xcd_logical(blockIdx.x, ntile * p.splitk);
-  const int slice = logical_all / ntile;
-  int tm, tn;
-  tile_of(logical_all - slice * ntile, p.tiles_m, p.tiles_n, tm, tn);
   const int64_t m0 = (int64_t)tm * P8_BM, n0 = (int64_t)tn * P8_BN;
   const int nk_all = (int)(p.K / P8_BK);
   const int kt0 = slice * p.ktiles_per;                   // this workgroup's K-tile range (split-K for wgrads)
   const int nk = (kt0 + p.ktiles_per < nk_all ? kt0 + p.ktiles_per : nk_all) - kt0;
   const int last_part = 4 * nk - 2;   // parts: -1 (A0 of tile 0), then per tile B0, B1, A1 and A0 of the next tile
+  PartBase8 pb;
+  if constexpr (!EDGE) {
+    const int r0 = tid >> 3, cpos = tid & 7;          // chunk j of a part: part row j*64 + r0, chunk column cpos
+    const int c = cpos ^ (r0 & 7);
+    const int rb = (r0 >> 5) * 64 + (r0 & 31);        // B parts interleave the four wave columns' 32-row halves
+    pb.voff_a = (unsigned)((r0 * p.lda + c * 8) * 2);
+    pb.voff_b = (unsigned)((rb * p.ldb + c * 8) * 2);
+    const char* a0 = (const char*)(p.A + m0 * p.lda + (int64_t)kt0 * P8_BK);
+    const char* b0 = (const char*)(p.B + n0 * p.ldb + (int64_t)kt0 * P8_BK);
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        pb.a[sub][j] = a0 + (int64_t)(j * 128 + sub * 64) * p.lda * 2;
+        pb.b[sub][j] = b0 + (int64_t)(j * 128 + sub * 32) * p.ldb * 2;
+      }
+  }
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -116,10 +160,10 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
   }
 
   // ---- prologue: parts -1 (A0 of tile 0), 0, 1, 2 in flight; part -1 landed for everyone
-  issue_part(p, -1, m0, n0, kt0, smem, tid, wave_u);
+  issue_part<EDGE>(p, pb, -1, m0, n0, kt0, smem, tid, wave_u);
 #pragma unroll
   for (int q = 0; q < 3; q++)
-    if (q <= last_part) issue_part(p, q, m0, n0, kt0, smem, tid, wave_u);
+    if (q <= last_part) issue_part<EDGE>(p, pb, q, m0, n0, kt0, smem, tid, wave_u);
   if (last_part >= 2) wait_vm<6>();
   else wait_vm<0>();
   bar();
@@ -131,7 +175,7 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) ra0[i][ks] = *(const bf16x8_t*)(slot + a_off[i][ks]);
-    if (3 <= last_part) issue_part(p, 3, m0, n0, kt0, smem, tid, wave_u);
+    if (3 <= last_part) issue_part<EDGE>(p, pb, 3, m0, n0, kt0, smem, tid, wave_u);
     if (3 <= last_part) wait_vm<6>();
     else wait_vm<0>();
   }
@@ -166,7 +210,7 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
           for (int ks = 0; ks < 2; ks++) ra0[i][ks] = *(const bf16x8_t*)(slot + a_off[i][ks]);
       }
       if (q + 4 <= last_part) {
-        issue_part(p, q + 4, m0, n0, kt0, smem, tid, wave_u);
+        issue_part<EDGE>(p, pb, q + 4, m0, n0, kt0, smem, tid, wave_u);
         wait_vm<6>();                              // part q+1 landed; q+2..q+4 in flight
       } else {                                     // tail: fewer younger parts behind part q+1
         const int younger = last_part - (q + 1);
@@ -228,6 +272,23 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
                                                     smem + wave_u * 16384))
     return;
   gemm_epilogue<EPI, 8, 4, /*INTERIOR_VARIANT=*/(EPI == EPI_F32)>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, slice);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_8phase_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int logical_all = xcd_logical(blockIdx.x, ntile * p.splitk);
+  const int slice = logical_all / ntile;
+  int tm, tn;
+  tile_of(logical_all - slice * ntile, p.tiles_m, p.tiles_n, tm, tn);
+#ifdef VJ_GEMM8_VADDR_ONLY   // A/B build: every tile on the per-chunk 64-bit addressing
+  const bool interior = false;
+#else
+  const bool interior = ((int64_t)(tm + 1) * P8_BM <= p.M) && ((int64_t)(tn + 1) * P8_BN <= p.N);   // workgroup-uniform
+#endif
+  if (interior) gemm8_body<EPI, false>(p, smem, tm, tn, slice);
+  else gemm8_body<EPI, true>(p, smem, tm, tn, slice);
 }
 
 __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, int64_t N, int64_t ldc, int S,
