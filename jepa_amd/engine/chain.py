@@ -67,6 +67,13 @@ class Workspace:
         return buf
 
 
+    @classmethod
+    def release(cls, prefix):
+        """Drop every buffer whose tag starts with `prefix` (a Trainer's namespace) -- called when the owner dies."""
+        for key in [k for k in cls._bufs if str(k[1]).startswith(prefix)]:
+            del cls._bufs[key]
+
+
 class TrunkCtx:
     """What `blocks_backward` needs from `blocks_forward`."""
     __slots__ = ("x_in", "ws", "M", "D", "segs", "seg_arr")

@@ -204,7 +204,8 @@ def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], sa
     return out, segs, saved
 
 
-def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_done=None, beta: float = 0.0):
+def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_done=None, beta: float = 0.0,
+                     ws_tag="bwd_tmp"):
     """dout [M, D] bf16: gradient of the encoder output rows.  Pixels need no gradient.  Parameter gradients are written
     as alpha * grad + beta * old (beta = 1 accumulates micro-batches)."""
     tok, saved_blocks, xl, mean, rstd = saved
@@ -213,7 +214,7 @@ def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_don
         side = side_stream(dout.device)
         dx = chain.blocks_backward(dx, saved_blocks, ew, alpha, side.stream.cuda_stream if side.enabled else None,
                                    (lambda li: on_layer_done("enc", li)) if on_layer_done is not None else None,
-                                   beta_acc=beta)
+                                   beta_acc=beta, tag=ws_tag)
     else:
         for li in range(len(ew.blocks) - 1, -1, -1):
             dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha, beta)
@@ -265,7 +266,8 @@ def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_p
     return zhat, tsegs, saved
 
 
-def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_layer_done=None, beta: float = 0.0):
+def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_layer_done=None, beta: float = 0.0,
+                       ws_tag="bwd_tmp"):
     """dzhat [sum_i B*Kp_i, D] bf16 -> returns dz [sum_i B*Ke_i, D] bf16 (gradient of the encoder output)."""
     z, e_shape, segs, tsegs, saved_blocks, t, tn, mean, rstd = saved
     Dp = pw.embed.w.shape[0]
@@ -283,7 +285,7 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
         side = side_stream(dzhat.device)
         dx = chain.blocks_backward(dx, saved_blocks, pw, alpha, side.stream.cuda_stream if side.enabled else None,
                                    (lambda li: on_layer_done("pred", li)) if on_layer_done is not None else None,
-                                   beta_acc=beta)
+                                   beta_acc=beta, tag=ws_tag)
     else:
         for li in range(len(pw.blocks) - 1, -1, -1):
             dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha, beta)

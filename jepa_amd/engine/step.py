@@ -19,7 +19,9 @@ from dataclasses import dataclass
 import torch
 
 from ..hip import ops
-from . import dp, optstate
+import weakref
+
+from . import chain, dp, optstate
 from .layers import encoder_backward, encoder_forward, predictor_backward, predictor_forward, side_stream
 from .weights import ParamArena, encoder_views, is_no_decay, predictor_views
 
@@ -119,6 +121,8 @@ class Trainer:
         if self.device.index is None:   # 'cuda' and 'cuda:0' must name the same streams / workspaces everywhere
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.micro_batch = micro_batch
+        self._ws = f"trainer{id(self)}:"   # workspace namespace: two Trainers in one process never share activations
+        weakref.finalize(self, chain.Workspace.release, self._ws)
         self.loss_exp, self.reg_coeff = float(loss_exp), float(reg_coeff)
         self.betas, self.eps, self.clip_grad = tuple(betas), float(eps), clip_grad
         self.check_finite = True   # always on and device-side (the argument is kept for API compatibility)
@@ -184,7 +188,7 @@ class Trainer:
     def forward_target(self, clips, masks_pred):
         """h_i = apply_masks(F.layer_norm(target_encoder(clips)), masks_pred)  (train.py:419-429), fp32."""
         B = clips.shape[0]
-        x, _, _ = encoder_forward(self.tw, clips, None, save=False, final_norm=False, ws_tag="tgt")
+        x, _, _ = encoder_forward(self.tw, clips, None, save=False, final_norm=False, ws_tag=self._ws + "tgt")
         N = self.tvit.num_patches
         return [ops.target_rows(x, self.tw.norm.g, self.tw.norm.b, mp, B, N, 1e-6, 1e-5) for mp in masks_pred]
 
@@ -230,8 +234,8 @@ class Trainer:
                     h = self.forward_target(cl, mp)
             else:
                 h = self.forward_target(cl, mp)
-            z, segs, saved_e = encoder_forward(self.ew, cl, me, save=True, ws_tag="enc_save")
-            zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, me, mp, save=True, ws_tag="pred_save")
+            z, segs, saved_e = encoder_forward(self.ew, cl, me, save=True, ws_tag=self._ws + "enc_save")
+            zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, me, mp, save=True, ws_tag=self._ws + "pred_save")
             mark('context+predictor forward (main stream)')
             if fwd_overlap:
                 side.join()
@@ -257,9 +261,11 @@ class Trainer:
             if last:
                 self.reducer.begin(side.stream if side.enabled else None)
             lhook = hook if last else None
-            dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=lhook, beta=beta)
+            dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=lhook, beta=beta,
+                                    ws_tag=self._ws + "bwd_tmp")
             mark('predictor backward (main stream)')
-            encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=lhook, beta=beta)
+            encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=lhook, beta=beta,
+                             ws_tag=self._ws + "bwd_tmp")
             mark('encoder backward (main stream)')
         ops.reg_finish(pstd, n_masks, self._stat[1:2])
         self.reducer.finish()

@@ -134,7 +134,12 @@ class VisionTransformer(nn.Module, hipmodule.HipModule):
         # (ViT-L B=24 forward: 728.7 -> 761.1 clips/s; ViT-H, whose 1280 = 5 x 256 columns tile the big kernel exactly: 405.6 vs
         # 395.9, so the wide models keep the automatic selection -- tools/infer_bench.py)
         flags = INFER_GEMM_FLAGS if self.embed_dim <= 1024 else 0
-        out, segs, _ = encoder_forward(ew, x, masks, save=False, ws_tag=f"infer{id(self)}", gemm_flags=flags)
+        tag = f"infer{id(self)}:"
+        if "_hip_ws_finalizer" not in self.__dict__:   # the workspace dies with the module
+            import weakref
+            from ...engine.chain import Workspace
+            self.__dict__["_hip_ws_finalizer"] = weakref.finalize(self, Workspace.release, tag)
+        out, segs, _ = encoder_forward(ew, x, masks, save=False, ws_tag=tag, gemm_flags=flags)
         return out, segs
 
 
