@@ -546,3 +546,33 @@ def test_full_size_step_vs_the_oracle_run_by_eager_pytorch_on_the_gpu():
         r = ref32["grads"][grp][name].reshape(g.shape).float()
         e = float((g - r).norm() / r.norm())
         assert e < 8e-2, (grp, name, e)
+
+
+@pytest.mark.timeout(900)
+def test_vit_huge_384_long_sequence_step_vs_gpu_eager_oracle():
+    """BASELINE configs[4] shape (ViT-H/16, 16x384x384 -> 4608 tokens, head_dim 80: the long-sequence attention path and
+    the 96-wide attention class inside a whole step), B=2, against the oracle run in fp32 by eager PyTorch on the same GPU:
+    loss <= 1e-3 relative, gradients rel-L2 <= 8e-2."""
+    from oracle import vjepa_oracle as O
+    from tests.step_util import VITH, VITL_MASKS
+    m = dict(VITH, crop=384, num_patches=8 * 24 * 24)
+    tr, state, _, _, _ = build_trainer(m, 2)
+    gens = O.make_mask_gens(VITL_MASKS, m["crop"], m["frames"], m["patch"], m["tubelet"])
+    clips, me, mp = draw_batch(gens, 2, m, 77, 78)
+    cd, med, mpd = to_dev(clips, me, mp)
+    st = {k: ({n: t.to(DEV) for n, t in v.items()} if k != "opt" else {}) for k, v in state.items()}
+    ref = O.train_step(st, cd, med, mpd, oracle_cfg(m, 2), dict(HP), 1)
+    out = tr.train_step(cd, med, mpd, lr=ref["lr"], wd=ref["wd"], ema=ref["ema"])
+    assert me[0].shape[1] + mp[0].shape[1] > 2500, "test setup: a long predictor sequence"
+    assert abs(out.loss - ref["loss"]) < 1e-3 * abs(ref["loss"]), (out.loss, ref["loss"])
+    worst = 0.0
+    for grp, name in (("enc", "blocks.0.attn.qkv.weight"), ("enc", "blocks.31.mlp.fc2.weight"), ("enc", "blocks.16.attn.proj.weight"),
+                      ("pred", "predictor_blocks.0.attn.qkv.weight"), ("pred", "predictor_blocks.11.mlp.fc1.weight"),
+                      ("enc", "patch_embed.proj.weight"), ("pred", "mask_tokens.0")):
+        g = tr.arena.grad(grp + "." + name).float()
+        r = ref["grads"][grp][name].reshape(g.shape).float()
+        e = float((g - r).norm() / r.norm())
+        worst = max(worst, e)
+        assert e < 8e-2, (grp, name, e)
+    print(f"ViT-H 16x384x384 B=2: HIP loss {out.loss:.6f} vs GPU-eager fp32 oracle {ref['loss']:.6f}; worst gradient rel-L2 {worst:.2e}; "
+          f"sequence lengths enc {[x.shape[1] for x in me]} pred {[x.shape[1] for x in mp]}")
