@@ -88,32 +88,6 @@ __device__ __forceinline__ void half_erfc2(f32x2_t x, f32x2_t& q, f32x2_t& gauss
   p = __builtin_elementwise_fma(p, t, c1);
   q = (p * t) * gauss;
 }
-#ifdef VJ_GELU_SCALAR
-// A/B variant: the same A-S 7.1.26 arithmetic written on scalars (no register-pair alignment moves)
-__device__ __forceinline__ void half_erfc1(float x, float& q, float& gauss) {
-  const float k = 0.3275911f * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(k, fabsf(x), 1.0f));
-  gauss = __builtin_amdgcn_exp2f((x * -0.72134752044448170f) * x);
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
-  q = (p * t) * gauss;
-}
-__device__ __forceinline__ float gelu1(float x) {
-  float q, g;
-  half_erfc1(x, q, g);
-  return fmaxf(x, 0.f) - fabsf(x * q);
-}
-__device__ __forceinline__ float dgelu1(float x) {
-  float q, g;
-  half_erfc1(x, q, g);
-  const float phi = 0.5f + copysignf(0.5f - q, x);
-  return fmaf(x * 0.3989422804014327f, g, phi);
-}
-__device__ __forceinline__ f32x2_t gelu2(f32x2_t x) { return (f32x2_t){gelu1(x[0]), gelu1(x[1])}; }
-__device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) { return (f32x2_t){dgelu1(x[0]), dgelu1(x[1])}; }
-#else
 // gelu(x) = x * Phi(x) = max(x, 0) - |x * q|
 __device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
   f32x2_t q, g;
@@ -130,7 +104,6 @@ __device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {
   const f32x2_t c = {0.3989422804014327f, 0.3989422804014327f};
   return __builtin_elementwise_fma(x * c, g, phi);
 }
-#endif
 
 // ---- host side error plumbing (no C++ exception crosses the C ABI) ----
 extern "C" const char* vj_last_error(void);
