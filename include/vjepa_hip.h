@@ -255,6 +255,14 @@ int vj_comm_allreduce_bucket(vj_comm_t comm, float* grad, int64_t count, vj_stre
 int vj_comm_broadcast(vj_comm_t comm, float* buf, int64_t count, int root, vj_stream_t stream);  /* parameter sync */
 int vj_comm_destroy(vj_comm_t comm);
 
+/* ---- run-time tuning switches ------------------------------------------------------------------------------
+ * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
+ * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_lanes", "wgrad_tn",
+ * "attn_bwd_fused", "reduce_inline", "gemm_dbg".  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
+int vj_set_option(const char* name, int value);
+int vj_get_option(const char* name, int* value);
+
 /* ---- hardware probes (tests / profiles only) ---------------------------------------------------------------- */
 int vj_probe_tr16(uint32_t* out256, int addr_scale, vj_stream_t stream);
 int vj_probe_copy(const void* src, void* dst, int64_t bytes, vj_stream_t stream);

@@ -13,6 +13,7 @@
 //   u [M,Dh] (pre-GELU), g [M,Dh], mean1 rstd1 mean2 rstd2 [M] fp32, lse2 [H*M] fp32 (per segment [B,H,S]).
 // With save = 0 (EMA target encoder, inference) one such set is reused by every block and x ping-pongs.
 #include "common.hpp"
+#include "options.hpp"
 #include "../../include/vjepa_hip.h"
 #include <atomic>
 #include <mutex>
@@ -140,9 +141,7 @@ extern "C" int vj_prof_collect(double* ms, double* flop, int64_t* launches, cons
 }
 
 // ---------------------------------------------------------------------------------------------------- launch helpers
-// GEMM kernel-selection flags per role (experiments: VJ_GEMM_FWD_FLAGS / VJ_GEMM_DGRAD_FLAGS, e.g. 256 = gemm4w.hip)
-static int g_fwd_flags = [] { const char* e = getenv("VJ_GEMM_FWD_FLAGS"); return e ? atoi(e) : 0; }();
-static int g_dgrad_flags = [] { const char* e = getenv("VJ_GEMM_DGRAD_FLAGS"); return e ? atoi(e) : 0; }();
+// GEMM kernel-selection flags per role: run-time options gemm_fwd_flags / gemm_dgrad_flags (options.hpp), e.g. 256 = gemm4w.hip
 static int gemm(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                 int64_t K, const float* bias, const void* res, int64_t ldr, const void* aux_in, void* aux_out,
                 int64_t ldaux, int epi, hipStream_t st, int flags = 0) {
@@ -210,7 +209,7 @@ static int check_segs(const vj_seg_t* segs, int64_t n_segs, int64_t M, const cha
 extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M,
                              int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save,
                              int gemm_flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
-  const int fwd_flags = gemm_flags ? gemm_flags : g_fwd_flags;
+  const int fwd_flags = gemm_flags ? gemm_flags : vj_opt(VJ_OPT_GEMM_FWD_FLAGS);
   CH(check_blocks(blocks, n_blocks, D, "vj_blocks_fwd"));
   CH(check_segs(segs, n_segs, M, "vj_blocks_fwd"));
   VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_fwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
@@ -306,7 +305,6 @@ extern "C" int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int6
 // bias reduction), two of them fill each other's launch gaps.  The lane is joined into `side` at the end of every block,
 // so the caller still sees ONE producer stream.
 static hipStream_t g_lane2 = nullptr;
-static int g_lanes = [] { const char* e = getenv("VJ_WGRAD_LANES"); return e ? atoi(e) : 1; }();
 static hipStream_t lane2() {
   static std::once_flag once;
   std::call_once(once, [] {
@@ -357,6 +355,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
   CH(check_segs(segs, n_segs, M, "vj_blocks_bwd"));
   VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_bwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
   if (M == 0) return 0;
+  const int g_dgrad_flags = vj_opt(VJ_OPT_GEMM_DGRAD_FLAGS);
   const int64_t Dh = blocks[0].fc1.n_out, hd = D / heads;
   const float scale = (float)pow((double)hd, -0.5);   // head_dim ** -0.5 exactly as Attention.scale (modules.py:53) is computed on the host
   const FwdLayout F = fwd_layout(M, D, Dh, heads);
@@ -373,7 +372,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
   }
   const char* sv = (const char*)save_ws;
   char* tmp = (char*)tmp_ws;
-  SideCtx sc{stream, side ? side : stream, (side && g_lanes >= 2) ? lane2() : nullptr, tmp, &L, M, alpha, beta_acc, flags & 1};
+  SideCtx sc{stream, side ? side : stream, (side && vj_opt(VJ_OPT_WGRAD_LANES) >= 2) ? lane2() : nullptr, tmp, &L, M, alpha, beta_acc, ((flags & 1) || vj_opt(VJ_OPT_WGRAD_TN)) ? 1 : 0};
   constexpr int MAX_BLOCKS = 256;
   VJ_CHECK_ARG(n_blocks <= MAX_BLOCKS, "vj_blocks_bwd: more than %d blocks", MAX_BLOCKS);
   hipEvent_t side_done[MAX_BLOCKS];

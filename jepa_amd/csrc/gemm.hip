@@ -14,6 +14,7 @@
 // CONSECUTIVE output columns: 8-byte bf16 / 16-byte fp32 epilogue accesses for C, bias, residual and aux.
 // Workgroup ids are remapped so every XCD (private L2) works on a contiguous band of tiles.
 #include "gemm_common.hpp"
+#include "options.hpp"
 #include <cstdlib>
 
 // tile configurations: <BM, BN, WM, WN> = block tile and wave grid; each wave owns (BM/WM) x (BN/WN)
@@ -283,7 +284,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     // 87.0 ms (8-phase) vs 90.0 ms (4-wave) per step, for every selection policy tried.  So it is opt-in: flags bit 8 or
     // VJ_GEMM_4W=1 (all forward / dgrad GEMMs), meant for single-stream use (inference, profiling).
     const int64_t t4w = cdiv64(a.M, 256) * cdiv64(a.N, 128);
-    static const int use_4w = [] { const char* e = getenv("VJ_GEMM_4W"); return e ? atoi(e) : 0; }();
+    const int use_4w = vj_opt(VJ_OPT_GEMM_4W);
     if (use_4w == 1 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 64)
       return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
@@ -332,8 +333,7 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.alpha = alpha; a.beta = beta;
   a.tiles_m = a.tiles_n = 0; a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
-  static const int dbg_env = [] { const char* e = getenv("VJ_GEMM_DBG"); return e ? atoi(e) : 0; }();
-  a.dbg = dbg_env;
+  a.dbg = vj_opt(VJ_OPT_GEMM_DBG);
   a.zero_row = nullptr;
   switch (epilogue) {
     case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, nullptr, 0, stream);

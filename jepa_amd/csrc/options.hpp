@@ -1,0 +1,22 @@
+// Run-time tuning switches of the library (vj_set_option / vj_get_option, include/vjepa_hip.h).
+//
+// Every switch selects between kernels that compute the SAME result (bit-identical unless the table below says
+// otherwise); they exist so that A/B measurements can be interleaved inside ONE process on one GPU (tools/abab.py):
+// box-to-box and thermal drift on MI355X is larger than most kernel-level deltas.  Initial values come from the
+// environment variable of the same name in upper case with a VJ_ prefix (VJ_GEMM_4W=1 ...), read once.
+#pragma once
+
+enum VjOpt {
+  VJ_OPT_GEMM_FWD_FLAGS = 0,   // vj_gemm_bf16_nt flags for the chains' forward GEMMs (0 = automatic selection)
+  VJ_OPT_GEMM_DGRAD_FLAGS,     // ... for the chains' dgrad GEMMs
+  VJ_OPT_GEMM_4W,              // 1: every forward / dgrad GEMM on the 4-wave 256x128 kernel; 2: per-shape policy
+  VJ_OPT_GEMM_PERSIST,         // 1: persistent 8-phase kernel (gemm8p.hip) where it applies
+  VJ_OPT_WGRAD_LANES,          // weight-gradient lanes of vj_blocks_bwd (1 or 2)
+  VJ_OPT_WGRAD_TN,             // 1: transpose-free weight gradients (gemm8_tn.hip) in the chains / engine
+  VJ_OPT_ATTN_BWD_FUSED,       // 1: single-pass attention backward (attention_bwd1.hip) where it applies
+  VJ_OPT_REDUCE_INLINE,        // 1: last-arriver reductions inside the producers (no reduce_partials / splitk_reduce launches)
+  VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)
+  VJ_OPT_COUNT
+};
+
+int vj_opt(int id);   // current value (relaxed atomic load; safe from any thread)

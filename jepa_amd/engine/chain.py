@@ -15,8 +15,6 @@ import torch
 
 from ..hip.lib import LAYER_CB, VjBlock, VjLinear, VjNorm, VjSeg, check, load_library
 
-WGRAD_TN = os.environ.get("VJ_WGRAD_TN", "0") == "1"
-
 
 def _p(t):
     return None if t is None else t.data_ptr()
@@ -131,7 +129,7 @@ def blocks_backward(dout, ctx, views, alpha, side_stream=None, on_layer_done=Non
         dout.record_stream(torch.cuda.ExternalStream(side_stream, device=dout.device))
     check(lib.vj_blocks_bwd(arr, n, ctx.x_in.data_ptr(), dout.data_ptr(), dx.data_ptr(), M, D, views.heads, ctx.seg_arr,
                             len(ctx.segs), alpha, beta_acc, ctx.ws.data_ptr(), ctx.ws.numel(), tmp.data_ptr(),
-                            tmp.numel(), 1 if WGRAD_TN else 0, torch.cuda.current_stream().cuda_stream, side_stream, cb,
+                            tmp.numel(), 0, torch.cuda.current_stream().cuda_stream, side_stream, cb,
                             None), "vj_blocks_bwd")
     if errs:
         raise errs[0]

@@ -10,8 +10,11 @@ step k computes:
 
 Two device slots and two pinned host slots per stream of tensors; the copy stream waits until the step that consumed a
 slot has been enqueued completely before overwriting it (event recorded on the compute stream at the following
-`next()`), and the compute stream waits on the copy's event -- no host synchronisation anywhere.  The fp32 -> bf16
-cast stays fused in `vj_tubelet_pack` (the copy moves the loader's fp32 pixels verbatim).
+`next()`), and the compute stream waits on the copy's event.  The only host-side wait is on the PINNED staging buffers:
+before the host memcpy of batch k+depth into a slot's pinned buffer, the host waits for the event recorded after the
+slot's previous H2D copy (batch k) -- normally long complete, so the wait is free, but without it a host that runs more
+than `depth` steps ahead of the GPU (loss read every N steps, pageable loader tensors) would overwrite pixels a DMA has
+not read yet.  The fp32 -> bf16 cast stays fused in `vj_tubelet_pack` (the copy moves the loader's fp32 pixels verbatim).
 """
 import torch
 
@@ -28,6 +31,7 @@ class DevicePrefetcher:
         self._host = [dict() for _ in range(depth)]    # slot -> {key: pinned tensor}
         self._dev = [dict() for _ in range(depth)]     # slot -> {key: device tensor}
         self._free_ev = [None] * depth                 # compute-stream event: slot's previous contents are consumed
+        self._h2d_done = [None] * depth                # copy-stream event: the slot's pinned buffers have been read
         self._slot = 0
         self._inflight = None                          # (slot, ready_event, structure)
         self._last_slot = None
@@ -56,6 +60,8 @@ class DevicePrefetcher:
         clip_list, masks_enc, masks_pred = self.fetch()
         slot = self._slot
         self._slot = (slot + 1) % self.depth
+        if self._h2d_done[slot] is not None:
+            self._h2d_done[slot].synchronize()         # the DMA engine is done with this slot's pinned staging buffers
         with torch.cuda.stream(self.copy_stream):
             if self._free_ev[slot] is not None:
                 self.copy_stream.wait_event(self._free_ev[slot])
@@ -64,6 +70,7 @@ class DevicePrefetcher:
             mp = [self._stage(slot, ("mp", i), m) for i, m in enumerate(masks_pred)]
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
+        self._h2d_done[slot] = ready
         self._inflight = (slot, ready, clips, me, mp)
 
     def next(self):

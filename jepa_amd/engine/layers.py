@@ -106,15 +106,15 @@ def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
 # Transpose-free weight gradients (vj_gemm_bf16_tn_splitk) are numerically equivalent and remove every activation
 # transpose, but on MI355X the step time is the same (277.4 vs 278.0 clips/s, same box): with 2 waves per SIMD the 8-byte
 # transpose reads run well below the LDS peak and the TN K loop is ~30 % slower than the NT one -- exactly what the
-# transposes cost.  Default: the NT route (the one profiled in profiles/); VJ_WGRAD_TN=1 selects the TN route.
-WGRAD_TN = os.environ.get("VJ_WGRAD_TN", "0") == "1"
+# transposes cost.  Default: the NT route; the run-time option "wgrad_tn" (VJ_WGRAD_TN=1) selects the TN route.
+from ..hip.lib import get_option as _get_option  # noqa: E402
 
 
 def _tn_ok(n_out: int, k_in: int) -> bool:
     """The transpose-free weight-gradient kernel works on 256 x 256 output tiles: use it where they are (nearly) full."""
     def waste(n):
         return ((n + 255) // 256 * 256) / n
-    return WGRAD_TN and n_out % 8 == 0 and k_in % 8 == 0 and waste(n_out) * waste(k_in) <= 1.10
+    return _get_option("wgrad_tn") == 1 and n_out % 8 == 0 and k_in % 8 == 0 and waste(n_out) * waste(k_in) <= 1.10
 
 
 def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0):

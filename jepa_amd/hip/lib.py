@@ -98,6 +98,8 @@ SIGNATURES = {
     "vj_comm_allreduce_bucket": (I32, [P, P, I64, P]),
     "vj_comm_broadcast": (I32, [P, P, I64, I32, P]),
     "vj_comm_destroy": (I32, [P]),
+    "vj_set_option": (I32, [ctypes.c_char_p, I32]),
+    "vj_get_option": (I32, [ctypes.c_char_p, ctypes.POINTER(I32)]),
     "vj_probe_tr16": (I32, [P, I32, P]),
     "vj_probe_copy": (I32, [P, P, I64, P]),
 }
@@ -139,3 +141,16 @@ def check(rc, what):
     if rc != 0:
         msg = load_library().vj_last_error()
         raise HipKernelError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def set_option(name, value):
+    """Run-time tuning switch of the library (include/vjepa_hip.h: vj_set_option); returns the previous value."""
+    old = get_option(name)
+    check(load_library().vj_set_option(name.encode(), int(value)), "vj_set_option")
+    return old
+
+
+def get_option(name):
+    v = I32(0)
+    check(load_library().vj_get_option(name.encode(), ctypes.byref(v)), "vj_get_option")
+    return int(v.value)

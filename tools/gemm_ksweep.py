@@ -12,7 +12,10 @@ from jepa_amd.hip import ops  # noqa: E402
 def main():
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
-    for M, N in ((37632, 3072), (37632, 1024), (256 * 256, 256)):
+    from jepa_amd.hip.lib import set_option
+    for M, N, dbg in ((37632, 3072, 0), (37632, 3072, 1), (37632, 1024, 0), (37632, 1024, 1), (256 * 256, 256, 0)):
+        set_option("gemm_dbg", dbg)
+        print(f"--- M={M} N={N} " + ("WITHOUT the epilogue (gemm_dbg=1)" if dbg else "full kernel"))
         rounds = -(-((M + 255) // 256 * ((N + 255) // 256)) // 256)
         pts = []
         for K in (128, 256, 512, 1024, 2048, 4096):
