@@ -17,9 +17,12 @@ workload run right after the un-instrumented timed region (`value` never include
 """
 import argparse
 import json
+import logging
 import os
 import sys
 import time
+
+logging.basicConfig(stream=sys.stderr, level=logging.INFO)   # stdout carries the ONE JSON line and nothing else
 
 # The step runs on up to five HIP streams (dgrad chain, weight-gradient / target-forward stream, gradient-communication
 # stream, RCCL's internal stream under torch.distributed, input copy stream).  ROCm maps streams onto 4 hardware queues
@@ -125,10 +128,20 @@ def cpu_baseline_subprocess(wl_name, budget_s=240):
 
 
 def cpu_baseline(wl_name):
-    """Pinned oracle (CPU port of the reference arithmetic) on a bounded sample of the same workload."""
-    from oracle import vjepa_oracle as O
+    """CPU baseline on a bounded sample of the same workload (B=2, 1 warm-up + 3 timed steps): the REAL reference when
+    /root/reference is present (build container; kind "reference", oracle/ref_cpu_step.py), otherwise -- on the GPU box,
+    where the reference cannot travel -- the pinned oracle, a CPU port of the same arithmetic (kind "port").  Both were
+    timed side by side on the build container: profiles/r03_cpu_reference.json (0.183 vs 0.175 clips/s, 8 threads)."""
+    from oracle import ref_cpu_step
     wl = WORKLOADS[wl_name]
     cores = min(os.cpu_count(), 64)   # torch CPU kernels stop scaling (and thrash) far below 256 threads
+    if ref_cpu_step.available():
+        n_timed = 3 if wl_name != "vittiny" else 10
+        v, times, threads = ref_cpu_step.time_reference(wl, HP, batch=2, timed=n_timed, threads=cores, log=log)
+        return {"value": round(v, 4), "unit": "clips/s", "cores": threads, "kind": "reference",
+                "sample": f"facebookresearch/jepa modules + init_opt AdamW + EMA (fp32) on the host cores, same model/masks, "
+                          f"B=2, 1 warm-up + {n_timed} timed steps, torch CPU kernels with {threads} threads"}
+    from oracle import vjepa_oracle as O
     torch.set_num_threads(cores)
     B = 2
     from jepa_amd.app.vjepa.utils import init_video_model

@@ -36,81 +36,71 @@ torch.manual_seed(_GLOBAL_SEED)
 logger = get_logger(__name__)
 
 
+_REQUIRED = object()
+# (attribute, YAML section, key, default, cast) -- the reference's config surface (app/vjepa/train.py:71-157) plus one
+# extension: optimization.micro_batch = clips per micro-batch inside one step (the 3072-clip ViT-H recipe puts 384 clips
+# on a GPU; their saved activations do not fit, so the step walks them with gradient accumulation -- same sums, the
+# collator still draws masks for the whole batch).
+_SCHEMA = (
+    ('load_model', 'meta', 'load_checkpoint', None, None), ('r_file', 'meta', 'read_checkpoint', None, None),
+    ('seed', 'meta', 'seed', _GLOBAL_SEED, None), ('save_every_freq', 'meta', 'save_every_freq', -1, None),
+    ('skip_batches', 'meta', 'skip_batches', -1, None), ('use_sdpa', 'meta', 'use_sdpa', False, None),
+    ('which_dtype', 'meta', 'dtype', _REQUIRED, None),
+    ('model_name', 'model', 'model_name', _REQUIRED, None), ('pred_depth', 'model', 'pred_depth', _REQUIRED, None),
+    ('pred_embed_dim', 'model', 'pred_embed_dim', _REQUIRED, None), ('uniform_power', 'model', 'uniform_power', True, None),
+    ('use_mask_tokens', 'model', 'use_mask_tokens', True, None),
+    ('zero_init_mask_tokens', 'model', 'zero_init_mask_tokens', True, None),
+    ('dataset_type', 'data', 'dataset_type', 'videodataset', None), ('mask_type', 'data', 'mask_type', 'multiblock3d', None),
+    ('dataset_paths', 'data', 'datasets', [], None), ('datasets_weights', 'data', 'datasets_weights', None, None),
+    ('batch_size', 'data', 'batch_size', _REQUIRED, None), ('num_clips', 'data', 'num_clips', _REQUIRED, None),
+    ('num_frames', 'data', 'num_frames', _REQUIRED, None), ('tubelet_size', 'data', 'tubelet_size', _REQUIRED, None),
+    ('sampling_rate', 'data', 'sampling_rate', None, None), ('duration', 'data', 'clip_duration', None, None),
+    ('crop_size', 'data', 'crop_size', 224, None), ('patch_size', 'data', 'patch_size', _REQUIRED, None),
+    ('pin_mem', 'data', 'pin_mem', False, None), ('num_workers', 'data', 'num_workers', 1, None),
+    ('filter_short_videos', 'data', 'filter_short_videos', False, None),
+    ('decode_one_clip', 'data', 'decode_one_clip', True, None),
+    ('loss_exp', 'loss', 'loss_exp', _REQUIRED, None), ('reg_coeff', 'loss', 'reg_coeff', _REQUIRED, None),
+    ('ipe', 'optimization', 'ipe', None, None), ('ipe_scale', 'optimization', 'ipe_scale', 1.0, None),
+    ('clip_grad', 'optimization', 'clip_grad', None, None), ('wd', 'optimization', 'weight_decay', _REQUIRED, float),
+    ('final_wd', 'optimization', 'final_weight_decay', _REQUIRED, float), ('num_epochs', 'optimization', 'epochs', _REQUIRED, None),
+    ('warmup', 'optimization', 'warmup', _REQUIRED, None), ('start_lr', 'optimization', 'start_lr', _REQUIRED, None),
+    ('lr', 'optimization', 'lr', _REQUIRED, None), ('final_lr', 'optimization', 'final_lr', _REQUIRED, None),
+    ('ema', 'optimization', 'ema', _REQUIRED, None), ('betas', 'optimization', 'betas', (0.9, 0.999), None),
+    ('eps', 'optimization', 'eps', 1.e-8, None), ('micro_batch', 'optimization', 'micro_batch', None, None),
+    ('folder', 'logging', 'folder', _REQUIRED, None), ('tag', 'logging', 'write_tag', _REQUIRED, None),
+)
+
+
+def _parse_config(args):
+    """YAML dict -> namespace.  Like the reference's chain of .get() calls, a key without a default that is missing reads
+    as None (and fails where it is first used); `cast` mirrors the reference's float() on the weight-decay keys."""
+    import types
+    cfg = types.SimpleNamespace()
+    for attr, section, key, default, cast in _SCHEMA:
+        sec = args.get(section) or {}
+        val = sec.get(key, None if default is _REQUIRED else default)
+        setattr(cfg, attr, cast(val) if (cast is not None and val is not None) else val)
+    return cfg
+
+
 def _with_module_prefix(sd):
     return {"module." + k: v for k, v in sd.items()}
 
 
 def main(args, resume_preempt=False):
-    # ----------------------------------------------------------------------- config (train.py:71-157)
-    cfgs_meta = args.get('meta')
-    load_model = cfgs_meta.get('load_checkpoint') or resume_preempt
-    r_file = cfgs_meta.get('read_checkpoint', None)
-    seed = cfgs_meta.get('seed', _GLOBAL_SEED)
-    save_every_freq = cfgs_meta.get('save_every_freq', -1)
-    skip_batches = cfgs_meta.get('skip_batches', -1)
-    use_sdpa = cfgs_meta.get('use_sdpa', False)
-    which_dtype = cfgs_meta.get('dtype')
-    logger.info(f'{which_dtype=}')
-    if which_dtype.lower() != 'bfloat16':
+    # config: the reference's YAML schema (app/vjepa/train.py:71-157) as a table -- see _SCHEMA below
+    cfg = _parse_config(args)
+    cfg.load_model = cfg.load_model or resume_preempt
+    logger.info(f'which_dtype={cfg.which_dtype!r}')
+    if str(cfg.which_dtype).lower() != 'bfloat16':
         raise NotImplementedError("meta.dtype must be bfloat16: the MI355X path computes in bf16 MFMA with fp32 "
                                   "accumulation and fp32 master weights (every shipped pretrain config uses bfloat16)")
-    mixed_precision = True
-
+    if cfg.datasets_weights is not None and len(cfg.datasets_weights) != len(cfg.dataset_paths):
+        raise AssertionError('Must have one sampling weight specified for each dataset')
     cfgs_mask = args.get('mask')
-    cfgs_model = args.get('model')
-    model_name = cfgs_model.get('model_name')
-    pred_depth = cfgs_model.get('pred_depth')
-    pred_embed_dim = cfgs_model.get('pred_embed_dim')
-    uniform_power = cfgs_model.get('uniform_power', True)
-    use_mask_tokens = cfgs_model.get('use_mask_tokens', True)
-    zero_init_mask_tokens = cfgs_model.get('zero_init_mask_tokens', True)
-
-    cfgs_data = args.get('data')
-    dataset_type = cfgs_data.get('dataset_type', 'videodataset')
-    mask_type = cfgs_data.get('mask_type', 'multiblock3d')
-    dataset_paths = cfgs_data.get('datasets', [])
-    datasets_weights = cfgs_data.get('datasets_weights', None)
-    if datasets_weights is not None:
-        assert len(datasets_weights) == len(dataset_paths), 'Must have one sampling weight specified for each dataset'
-    batch_size = cfgs_data.get('batch_size')
-    num_clips = cfgs_data.get('num_clips')
-    num_frames = cfgs_data.get('num_frames')
-    tubelet_size = cfgs_data.get('tubelet_size')
-    sampling_rate = cfgs_data.get('sampling_rate')
-    duration = cfgs_data.get('clip_duration', None)
-    crop_size = cfgs_data.get('crop_size', 224)
-    patch_size = cfgs_data.get('patch_size')
-    pin_mem = cfgs_data.get('pin_mem', False)
-    num_workers = cfgs_data.get('num_workers', 1)
-    filter_short_videos = cfgs_data.get('filter_short_videos', False)
-    decode_one_clip = cfgs_data.get('decode_one_clip', True)
-
-    cfgs_loss = args.get('loss')
-    loss_exp = cfgs_loss.get('loss_exp')
-    reg_coeff = cfgs_loss.get('reg_coeff')
-
-    cfgs_opt = args.get('optimization')
-    ipe = cfgs_opt.get('ipe', None)
-    ipe_scale = cfgs_opt.get('ipe_scale', 1.0)
-    clip_grad = cfgs_opt.get('clip_grad', None)
-    wd = float(cfgs_opt.get('weight_decay'))
-    final_wd = float(cfgs_opt.get('final_weight_decay'))
-    num_epochs = cfgs_opt.get('epochs')
-    warmup = cfgs_opt.get('warmup')
-    start_lr = cfgs_opt.get('start_lr')
-    lr = cfgs_opt.get('lr')
-    final_lr = cfgs_opt.get('final_lr')
-    ema = cfgs_opt.get('ema')
-    betas = cfgs_opt.get('betas', (0.9, 0.999))
-    eps = cfgs_opt.get('eps', 1.e-8)
-    # extension key (absent from the reference schema): clips per micro-batch inside one step.  The 3072-clip ViT-H
-    # recipe puts 384 clips on a GPU; their saved activations do not fit, so the step walks them in micro-batches with
-    # gradient accumulation -- same sums, the collator still draws masks for the whole batch
-    micro_batch = cfgs_opt.get('micro_batch', None)
-
-    cfgs_logging = args.get('logging')
-    folder = cfgs_logging.get('folder')
-    tag = cfgs_logging.get('write_tag')
+    mixed_precision = True
+    seed, ipe, num_epochs, warmup, clip_grad = cfg.seed, cfg.ipe, cfg.num_epochs, cfg.warmup, cfg.clip_grad
+    batch_size, folder, tag = cfg.batch_size, cfg.folder, cfg.tag
 
     np.random.seed(seed)
     torch.manual_seed(seed)
@@ -129,34 +119,34 @@ def main(args, resume_preempt=False):
     log_file = os.path.join(folder, f'{tag}_r{rank}.csv')
     latest_path = os.path.join(folder, f'{tag}-latest.pth.tar')
     load_path = None
-    if load_model:
-        load_path = os.path.join(folder, r_file) if r_file is not None else latest_path
+    if cfg.load_model:
+        load_path = os.path.join(folder, cfg.r_file) if cfg.r_file is not None else latest_path
         if not os.path.exists(load_path):
-            load_path, load_model = None, False
+            load_path, cfg.load_model = None, False
 
     csv_logger = CSVLogger(log_file, ('%d', 'epoch'), ('%d', 'itr'), ('%.5f', 'loss'), ('%.5f', 'loss-jepa'),
                            ('%.5f', 'reg-loss'), ('%.5f', 'enc-grad-norm'), ('%.5f', 'pred-grad-norm'),
                            ('%d', 'gpu-time(ms)'), ('%d', 'wall-time(ms)'))
 
     encoder, predictor = init_video_model(
-        uniform_power=uniform_power, use_mask_tokens=use_mask_tokens, num_mask_tokens=len(cfgs_mask),
-        zero_init_mask_tokens=zero_init_mask_tokens, device='cpu', patch_size=patch_size, num_frames=num_frames,
-        tubelet_size=tubelet_size, model_name=model_name, crop_size=crop_size, pred_depth=pred_depth,
-        pred_embed_dim=pred_embed_dim, use_sdpa=use_sdpa)
+        uniform_power=cfg.uniform_power, use_mask_tokens=cfg.use_mask_tokens, num_mask_tokens=len(cfgs_mask),
+        zero_init_mask_tokens=cfg.zero_init_mask_tokens, device='cpu', patch_size=cfg.patch_size, num_frames=cfg.num_frames,
+        tubelet_size=cfg.tubelet_size, model_name=cfg.model_name, crop_size=cfg.crop_size, pred_depth=cfg.pred_depth,
+        pred_embed_dim=cfg.pred_embed_dim, use_sdpa=cfg.use_sdpa)
     target_encoder = copy.deepcopy(encoder)
     for p in target_encoder.parameters():
         p.requires_grad = False
 
-    collator_cls = MB3DMaskCollator if mask_type == 'multiblock3d' else TubeMaskCollator
-    mask_collator = collator_cls(crop_size=crop_size, num_frames=num_frames, patch_size=patch_size,
-                                 tubelet_size=tubelet_size, cfgs_mask=cfgs_mask)
+    collator_cls = MB3DMaskCollator if cfg.mask_type == 'multiblock3d' else TubeMaskCollator
+    mask_collator = collator_cls(crop_size=cfg.crop_size, num_frames=cfg.num_frames, patch_size=cfg.patch_size,
+                                 tubelet_size=cfg.tubelet_size, cfgs_mask=cfgs_mask)
 
     (unsupervised_loader, unsupervised_sampler) = init_data(
-        data=dataset_type, root_path=dataset_paths, batch_size=batch_size, training=True, clip_len=num_frames,
-        frame_sample_rate=sampling_rate, filter_short_videos=filter_short_videos, decode_one_clip=decode_one_clip,
-        duration=duration, num_clips=num_clips, transform=None, datasets_weights=datasets_weights,
-        collator=mask_collator, num_workers=num_workers, world_size=world_size, pin_mem=pin_mem, rank=rank,
-        log_dir=None, crop_size=crop_size)
+        data=cfg.dataset_type, root_path=cfg.dataset_paths, batch_size=batch_size, training=True, clip_len=cfg.num_frames,
+        frame_sample_rate=cfg.sampling_rate, filter_short_videos=cfg.filter_short_videos, decode_one_clip=cfg.decode_one_clip,
+        duration=cfg.duration, num_clips=cfg.num_clips, transform=None, datasets_weights=cfg.datasets_weights,
+        collator=mask_collator, num_workers=cfg.num_workers, world_size=world_size, pin_mem=cfg.pin_mem, rank=rank,
+        log_dir=None, crop_size=cfg.crop_size)
     try:
         _dlen = len(unsupervised_loader)
     except Exception:
@@ -166,21 +156,21 @@ def main(args, resume_preempt=False):
     logger.info(f'iterations per epoch/dataest length: {ipe}/{_dlen}')
 
     optimizer, scaler, scheduler, wd_scheduler = init_opt(
-        encoder=encoder, predictor=predictor, target_encoder=target_encoder, wd=wd, final_wd=final_wd,
-        start_lr=start_lr, ref_lr=lr, final_lr=final_lr, iterations_per_epoch=ipe, warmup=warmup,
-        num_epochs=num_epochs, ipe_scale=ipe_scale, mixed_precision=mixed_precision, betas=betas, eps=eps,
-        loss_exp=loss_exp, reg_coeff=reg_coeff, clip_grad=clip_grad, world_size=world_size, device=device,
-        micro_batch=micro_batch)
+        encoder=encoder, predictor=predictor, target_encoder=target_encoder, wd=cfg.wd, final_wd=cfg.final_wd,
+        start_lr=cfg.start_lr, ref_lr=cfg.lr, final_lr=cfg.final_lr, iterations_per_epoch=ipe, warmup=warmup,
+        num_epochs=num_epochs, ipe_scale=cfg.ipe_scale, mixed_precision=mixed_precision, betas=cfg.betas, eps=cfg.eps,
+        loss_exp=cfg.loss_exp, reg_coeff=cfg.reg_coeff, clip_grad=clip_grad, world_size=world_size, device=device,
+        micro_batch=cfg.micro_batch)
     trainer = optimizer
     dp.broadcast_parameters(trainer.arena, trainer.tarena)   # DDP's one-time parameter sync (train.py:295-297)
     if world_size > 1:
         trainer.sync_shadows()
 
-    momentum_scheduler = (ema[0] + i * (ema[1] - ema[0]) / (ipe * num_epochs * ipe_scale)
-                          for i in range(int(ipe * num_epochs * ipe_scale) + 1))
+    momentum_scheduler = (cfg.ema[0] + i * (cfg.ema[1] - cfg.ema[0]) / (ipe * num_epochs * cfg.ipe_scale)
+                          for i in range(int(ipe * num_epochs * cfg.ipe_scale) + 1))
 
     start_epoch = 0
-    if load_model or os.path.exists(latest_path):
+    if cfg.load_model or os.path.exists(latest_path):
         # like the reference (train.py:307-320): with meta.load_checkpoint unset, load_path is None, the load fails, is
         # logged and training starts at epoch 0 -- an existing `-latest` file in a reused folder is NOT auto-resumed
         encoder, predictor, target_encoder, optimizer, scaler, start_epoch = load_checkpoint(
@@ -201,7 +191,7 @@ def main(args, resume_preempt=False):
             'opt': optimizer.state_dict(),
             'scaler': None if scaler is None else scaler.state_dict(),
             'target_encoder': _with_module_prefix(target_encoder.state_dict()),
-            'epoch': epoch, 'loss': loss_meter.avg, 'batch_size': batch_size, 'world_size': world_size, 'lr': lr,
+            'epoch': epoch, 'loss': loss_meter.avg, 'batch_size': batch_size, 'world_size': world_size, 'lr': cfg.lr,
         }
         try:
             torch.save(save_dict, path)
@@ -210,9 +200,9 @@ def main(args, resume_preempt=False):
 
     logger.info('Initializing loader...')
     loader = iter(unsupervised_loader)
-    if skip_batches > 0:
+    if cfg.skip_batches > 0:
         unsupervised_sampler.set_epoch(start_epoch)
-        for itr in range(skip_batches):
+        for itr in range(cfg.skip_batches):
             try:
                 next(loader)
             except Exception:
@@ -232,7 +222,7 @@ def main(args, resume_preempt=False):
         return udata[0], masks_enc, masks_pred
 
     # load_clips (train.py:391-408) one batch ahead: pinned staging + copy stream, see engine/input.py
-    prefetcher = DevicePrefetcher(fetch_host_batch, device, batch_size=batch_size, num_clips=num_clips)
+    prefetcher = DevicePrefetcher(fetch_host_batch, device, batch_size=batch_size, num_clips=cfg.num_clips)
 
     for epoch in range(start_epoch, num_epochs):
         logger.info('Epoch %d' % (epoch + 1))
@@ -244,7 +234,7 @@ def main(args, resume_preempt=False):
 
         for itr in range(ipe):
             itr_start_time = time.time()
-            clips, masks_enc, masks_pred = prefetcher.next()
+            clips, masks_enc, masks_pred = prefetcher.next(lookahead=(itr != ipe - 1))   # never across an epoch boundary
             for _i, m in enumerate(mask_meters):
                 m.update(masks_enc[_i][0].size(-1))
 
@@ -302,5 +292,5 @@ def main(args, resume_preempt=False):
         logger.info('avg. loss %.3f' % loss_meter.avg)
         if epoch % checkpoint_freq == 0 or epoch == (num_epochs - 1):
             save_checkpoint(epoch + 1, latest_path)
-            if save_every_freq > 0 and epoch % save_every_freq == 0:
+            if cfg.save_every_freq > 0 and epoch % cfg.save_every_freq == 0:
                 save_checkpoint(epoch + 1, os.path.join(folder, f'{tag}-e{epoch}.pth.tar'))

@@ -12,7 +12,7 @@ enum VjOpt {
   VJ_OPT_GEMM_4W,              // 1: every forward / dgrad GEMM on the 4-wave 256x128 kernel; 2: per-shape policy
   VJ_OPT_GEMM_PERSIST,         // 1: persistent 8-phase kernel (gemm8p.hip) where it applies
   VJ_OPT_WGRAD_LANES,          // weight-gradient lanes of vj_blocks_bwd (1 or 2)
-  VJ_OPT_WGRAD_TN,             // 1: transpose-free weight gradients (gemm8_tn.hip) in the chains / engine
+  VJ_OPT_WGRAD_TN,             // 1 (default): transpose-free weight gradients (gemm8_tn.hip); 0: transposes + NT GEMM
   VJ_OPT_ATTN_BWD_FUSED,       // 1: single-pass attention backward (attention_bwd1.hip) where it applies
   VJ_OPT_REDUCE_INLINE,        // 1: last-arriver reductions inside the producers (no reduce_partials / splitk_reduce launches)
   VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)

@@ -10,7 +10,7 @@ layer chain, so `loss.backward()` + any torch optimizer keep working on these mo
 """
 import torch
 
-from .weights import ParamArena
+from .weights import ARENA_GENERATION, ParamArena
 
 
 def require_gpu(t, what):
@@ -51,7 +51,7 @@ class HipModule:
                   "names": [n for n, _ in weights]}
             self.__dict__["_hip_private"] = st
         arena = st["arena"]
-        version = sum(p._version for _, p in params)
+        version = (ARENA_GENERATION[0], sum(p._version for _, p in params))
         if st["version"] != version:
             arena.refresh_bf16()
             if st["has_T"]:

@@ -73,9 +73,12 @@ class DevicePrefetcher:
         self._h2d_done[slot] = ready
         self._inflight = (slot, ready, clips, me, mp)
 
-    def next(self):
+    def next(self, lookahead=True):
         """Device tensors of the next batch (clips concatenated over num_clips, masks batch-repeated like
-        train.py:398-406); starts copying the batch after it."""
+        train.py:398-406); starts copying the batch after it unless lookahead=False.  The train loop passes
+        lookahead=False on the last iteration of an epoch: the reference re-creates its loader iterator at the first
+        `next(loader)` of the next epoch, i.e. AFTER `sampler.set_epoch(epoch + 1)` (train.py:366-381) -- fetching across
+        the boundary would permute epoch e+1 with epoch e's seed and draw one batch too many at the end of training."""
         cur = torch.cuda.current_stream()
         if self._last_slot is not None:   # everything that read the previous batch has been enqueued by now
             ev = torch.cuda.Event()
@@ -87,10 +90,11 @@ class DevicePrefetcher:
         self._inflight = None
         cur.wait_event(ready)
         self._last_slot = slot
-        try:
-            self._launch()               # batch k+1 overlaps step k
-        except StopIteration:
-            self._inflight = None
+        if lookahead:
+            try:
+                self._launch()           # batch k+1 overlaps step k
+            except StopIteration:
+                self._inflight = None
         clips_d = clips[0] if len(clips) == 1 else torch.cat(clips, dim=0)
         if self.batch_size is not None:
             me = [repeat_interleave_batch(m, self.batch_size, repeat=self.num_clips) for m in me]

@@ -103,18 +103,15 @@ def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
     return x2, saved
 
 
-# Transpose-free weight gradients (vj_gemm_bf16_tn_splitk) are numerically equivalent and remove every activation
-# transpose, but on MI355X the step time is the same (277.4 vs 278.0 clips/s, same box): with 2 waves per SIMD the 8-byte
-# transpose reads run well below the LDS peak and the TN K loop is ~30 % slower than the NT one -- exactly what the
-# transposes cost.  Default: the NT route; the run-time option "wgrad_tn" (VJ_WGRAD_TN=1) selects the TN route.
+# Weight gradients: transpose-free by default (vj_gemm_bf16_tn_splitk reads dY and X token-major as the backward produced
+# them; round-3 interleaved A/B at ViT-L B=24: 86.38 vs 86.83 ms/step, faster in 8 of 8 rounds, -25 W, and the 294
+# transpose launches / 35 GB per step of the NT route are gone -- profiles/r03_abab_switches.md).  The run-time option
+# "wgrad_tn" = 0 (VJ_WGRAD_TN=0) selects the transposes + NT split-K route, kept as the cross-check of the TN kernel.
 from ..hip.lib import get_option as _get_option  # noqa: E402
 
 
 def _tn_ok(n_out: int, k_in: int) -> bool:
-    """The transpose-free weight-gradient kernel works on 256 x 256 output tiles: use it where they are (nearly) full."""
-    def waste(n):
-        return ((n + 255) // 256 * 256) / n
-    return _get_option("wgrad_tn") == 1 and n_out % 8 == 0 and k_in % 8 == 0 and waste(n_out) * waste(k_in) <= 1.10
+    return _get_option("wgrad_tn") == 1 and n_out % 8 == 0 and k_in % 8 == 0
 
 
 def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0):

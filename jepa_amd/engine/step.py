@@ -23,7 +23,7 @@ import weakref
 
 from . import chain, dp, optstate
 from .layers import encoder_backward, encoder_forward, predictor_backward, predictor_forward, side_stream
-from .weights import ParamArena, encoder_views, is_no_decay, predictor_views
+from .weights import ParamArena, bump_generation, encoder_views, is_no_decay, predictor_views
 
 
 class _TargetArena:
@@ -271,6 +271,7 @@ class Trainer:
         self.reducer.finish()
         # ---- clip / AdamW / EMA / bf16 re-cast (train.py:461-487)
         clipped = bool(clip_now and self.clip_grad is not None)
+        self._last_clip = float(self.clip_grad) if clipped else 0.0
         self.optimizer_step(lr, wd, ema, clip_now)
         mark('wgrad stream joined + AdamW/EMA')
         return StepOutput(self._stat.clone(), self.reg_coeff, lr, wd, ema, clipped, 1.0 / self.world_size)
@@ -324,6 +325,7 @@ class Trainer:
                                   b2, self.eps, inv_world, ema, gstat, 0 if is_enc else 1, clip, inv_world,
                                   self._step_dev)
         A.refresh_transposed()
+        bump_generation()   # parameters changed behind torch's version counters: derived-weight caches must refresh
         for g in self.param_groups:
             g["lr"] = lr
             if not g.get("WD_exclude", False):
@@ -340,7 +342,10 @@ class Trainer:
         if self._gs_desc is None:
             order = [("enc", a, n, p) for a, n, p in self._enc_named if p.requires_grad]
             order += [("pred", a, n, p) for a, n, p in self._pred_named if p.requires_grad]
-            self._gs_meta = [(which, n, self.arena.slots[a].numel, not is_no_decay(n, p)) for which, a, n, p in order]
+            # "weight matrix" exactly as the reference's grad_logger filters (src/utils/logging.py:91-105): not a
+            # `.bias`, not 1-D -- which is NOT the optimizer's no-decay rule ('bias' anywhere in the name)
+            self._gs_meta = [(which, n, self.arena.slots[a].numel, not (n.endswith('.bias') or p.dim() == 1))
+                             for which, a, n, p in order]
             flat = []
             for which, a, n, p in order:
                 flat += [self.arena.slots[a].off, self.arena.slots[a].numel]
@@ -348,9 +353,17 @@ class Trainer:
         A = self.arena
         sums = ops.grad_stats_multi(A.G, A.M1, A.M2, self._gs_desc, len(self._gs_meta)).tolist()
         inv_world = 1.0 / self.world_size
+        # the reference logs AFTER clip_grad_norm_ (train.py:466-481): the arena keeps the unclipped gradients (the clip
+        # coefficient is applied inside the fused AdamW kernel), so the same coefficient is applied to the logged norms
+        fac = {"enc": 1.0, "pred": 1.0}
+        clip = getattr(self, "_last_clip", 0.0)
+        if clip > 0.0:
+            h = self._stat.tolist()
+            for which, i in (("enc", 4), ("pred", 6)):
+                fac[which] = min(1.0, clip / (math.sqrt(h[i]) * inv_world + 1e-6))
         out = {"enc": {"grads": [], "moments": []}, "pred": {"grads": [], "moments": []}}
         for (which, n, numel, is_mat), (sq, a1, a2) in zip(self._gs_meta, sums):
-            out[which]["grads"].append((n, math.sqrt(sq) * inv_world, is_mat))
+            out[which]["grads"].append((n, math.sqrt(sq) * inv_world * fac[which], is_mat))
             out[which]["moments"].append((a1 / numel, a2 / numel))
         self._arena_stats = out
         return out
@@ -377,3 +390,4 @@ class Trainer:
         self.arena.refresh_bf16()
         self.arena.refresh_transposed()
         self.tarena.refresh_bf16()
+        bump_generation()

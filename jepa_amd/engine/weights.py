@@ -18,6 +18,16 @@ import torch
 
 from ..hip import ops
 
+# Bumped whenever parameters are rewritten through raw arena pointers (the fused AdamW / EMA kernels, shadow refreshes):
+# torch's per-tensor `_version` counters do not see those writes, so every cache of derived weights (bf16 copies of
+# stand-alone modules, private arenas of engine/hipmodule.py) keys on this generation as well.
+ARENA_GENERATION = [0]
+
+
+def bump_generation():
+    ARENA_GENERATION[0] += 1
+
+
 from .optstate import ALIGN, Slot as _Slot, is_no_decay, layout, pad64 as _pad  # noqa: F401  (pure, CPU-testable)
 
 

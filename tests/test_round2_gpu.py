@@ -22,6 +22,23 @@ def _gens(masks=TINY_MASKS, m=TINY):
     return O.make_mask_gens(masks, m["crop"], m["frames"], m["patch"], m["tubelet"])
 
 
+
+def _arena_wide_gradient_check(tr, ref_grads, bound, what):
+    """EVERY trainable tensor of encoder and predictor: rel-L2 of the HIP gradient (arena view) against the oracle's.
+    Returns (worst value, its name); asserts every tensor under `bound` and prints the five worst."""
+    errs = []
+    for grp in ("enc", "pred"):
+        for name, r in ref_grads[grp].items():
+            g = tr.arena.grad(grp + "." + name).float()
+            r = r.reshape(g.shape).float().to(g.device)
+            errs.append((float((g - r).norm() / r.norm().clamp_min(1e-30)), grp + "." + name))
+    errs.sort(reverse=True)
+    print(f"{what}: {len(errs)} gradient tensors, worst rel-L2 " + ", ".join(f"{n} {e:.2e}" for e, n in errs[:5]))
+    bad = [(n, e) for e, n in errs if not e < bound]
+    assert not bad, (what, bad[:10])
+    return errs[0]
+
+
 # ------------------------------------------------------------------------------------------------ launch chains
 def test_c_chain_is_bit_identical_to_python_chain():
     """vj_blocks_fwd / vj_blocks_bwd enqueue the same kernels in the same order as the per-kernel Python chain:
@@ -248,7 +265,7 @@ def _dp_worker(rank, world, port, q):
                                   ("pred", "mask_tokens.0"), ("pred", "predictor_embed.bias")):
                     g = tr.arena.grad(grp + "." + name).float().cpu() * inv        # arena holds the SUM over ranks
                     r = ref["grads"][grp][name].reshape(g.shape)
-                    assert rel_l2(g, r) < 8e-2, (step, grp, name, rel_l2(g, r))
+                    assert rel_l2(g, r) < 3e-2, (step, grp, name, rel_l2(g, r))
         # every rank holds the same weights after the averaged update
         mine = tr.arena.P.clone()
         other = mine.clone()
@@ -273,7 +290,7 @@ def _dp_worker(rank, world, port, q):
 def test_two_rank_step_on_one_gpu_matches_oracle_with_averaged_gradients():
     """DDP numerics (train.py:295-297) before an 8-GPU box exists: two processes on cuda:0, gloo backend, different
     clips and different mask sizes per rank; the bucketed reducer runs its real hook / stream / event path.  Gradients
-    (arena SUM / world) vs the oracle's rank-averaged gradients: rel-L2 <= 8e-2; weights equal across ranks bit for bit
+    (arena SUM / world) vs the oracle's rank-averaged gradients: rel-L2 <= 3e-2; weights equal across ranks bit for bit
     and within 2.5*lr of the oracle's."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -503,7 +520,8 @@ def test_full_size_step_vs_the_oracle_run_by_eager_pytorch_on_the_gpu():
     """Parity at the benched batch in seconds instead of minutes: the oracle (the reference's arithmetic as plain torch
     functions) executed by stock PyTorch-ROCm eager on the SAME GPU -- fp32, and under autocast(bf16) as the reference runs on
     a GPU (train.py:419-438) -- against the HIP step on identical weights / clips / masks, ViT-L/16 16x224x224, B=24.
-    Loss within 1e-3 relative of the fp32 run (north-star bound) and of the autocast run; prints the eager step time as the
+    Loss within 1e-3 relative of the fp32 run (north-star bound) and of the autocast run; every gradient tensor of the arena
+    within 3e-2 rel-L2 of the fp32 run; prints the eager step time as the
     "reference on the same MI355X" context figure.  The oracle is the checker here, never the product."""
     import time
     from oracle import vjepa_oracle as O
@@ -540,19 +558,15 @@ def test_full_size_step_vs_the_oracle_run_by_eager_pytorch_on_the_gpu():
           f" | eager autocast-bf16 {res['autocast-bf16'][0]['loss']:.6f} ({24 / res['autocast-bf16'][1]:.1f} clips/s)")
     assert abs(out.loss - ref32["loss"]) < 1e-3 * abs(ref32["loss"]), (out.loss, ref32["loss"])
     assert abs(out.loss - res["autocast-bf16"][0]["loss"]) < 1e-3 * abs(ref32["loss"])
-    for grp, name in (("enc", "blocks.0.attn.qkv.weight"), ("enc", "blocks.23.mlp.fc2.weight"),
-                      ("pred", "predictor_blocks.0.attn.qkv.weight"), ("enc", "patch_embed.proj.weight")):
-        g = tr.arena.grad(grp + "." + name).float()
-        r = ref32["grads"][grp][name].reshape(g.shape).float()
-        e = float((g - r).norm() / r.norm())
-        assert e < 8e-2, (grp, name, e)
+    # arena-wide: every gradient tensor of the step at the benched size, rel-L2 <= 3e-2 (measured 6e-3 .. 1.4e-2 in round 2)
+    _arena_wide_gradient_check(tr, ref32["grads"], 3e-2, "ViT-L/16 B=24 vs GPU-eager fp32 oracle")
 
 
 @pytest.mark.timeout(900)
 def test_vit_huge_384_long_sequence_step_vs_gpu_eager_oracle():
     """BASELINE configs[4] shape (ViT-H/16, 16x384x384 -> 4608 tokens, head_dim 80: the long-sequence attention path and
     the 96-wide attention class inside a whole step), B=2, against the oracle run in fp32 by eager PyTorch on the same GPU:
-    loss <= 1e-3 relative, gradients rel-L2 <= 8e-2."""
+    loss <= 1e-3 relative, EVERY gradient tensor rel-L2 <= 3e-2."""
     from oracle import vjepa_oracle as O
     from tests.step_util import VITH, VITL_MASKS
     m = dict(VITH, crop=384, num_patches=8 * 24 * 24)
@@ -565,15 +579,7 @@ def test_vit_huge_384_long_sequence_step_vs_gpu_eager_oracle():
     out = tr.train_step(cd, med, mpd, lr=ref["lr"], wd=ref["wd"], ema=ref["ema"])
     assert me[0].shape[1] + mp[0].shape[1] > 2500, "test setup: a long predictor sequence"
     assert abs(out.loss - ref["loss"]) < 1e-3 * abs(ref["loss"]), (out.loss, ref["loss"])
-    worst = 0.0
-    for grp, name in (("enc", "blocks.0.attn.qkv.weight"), ("enc", "blocks.31.mlp.fc2.weight"), ("enc", "blocks.16.attn.proj.weight"),
-                      ("pred", "predictor_blocks.0.attn.qkv.weight"), ("pred", "predictor_blocks.11.mlp.fc1.weight"),
-                      ("enc", "patch_embed.proj.weight"), ("pred", "mask_tokens.0")):
-        g = tr.arena.grad(grp + "." + name).float()
-        r = ref["grads"][grp][name].reshape(g.shape).float()
-        e = float((g - r).norm() / r.norm())
-        worst = max(worst, e)
-        assert e < 8e-2, (grp, name, e)
+    worst, worst_name = _arena_wide_gradient_check(tr, ref["grads"], 3e-2, "ViT-H/16 16x384x384 B=2 vs GPU-eager fp32 oracle")
     print(f"ViT-H 16x384x384 B=2: HIP loss {out.loss:.6f} vs GPU-eager fp32 oracle {ref['loss']:.6f}; worst gradient rel-L2 {worst:.2e}; "
           f"sequence lengths enc {[x.shape[1] for x in me]} pred {[x.shape[1] for x in mp]}")
 

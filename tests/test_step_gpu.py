@@ -199,7 +199,7 @@ def test_vit_tiny_step_vs_oracle():
                             wd=ref["wd"], ema=ref["ema"])
         assert abs(out.loss - ref["loss"]) < 1e-3 * abs(ref["loss"]), (step, out.loss, ref["loss"])
         gq = tr.arena.grad("enc.blocks.11.attn.qkv.weight").float().cpu()
-        assert rel_l2(gq, ref["grads"]["enc"]["blocks.11.attn.qkv.weight"]) < 8e-2
+        assert rel_l2(gq, ref["grads"]["enc"]["blocks.11.attn.qkv.weight"]) < 3e-2
         gp = tr.arena.grad("enc.patch_embed.proj.weight").float().cpu()
         assert cosine(gp, ref["grads"]["enc"]["patch_embed.proj.weight"]) > 0.99
     w = tr.arena.f32("enc.blocks.0.mlp.fc1.weight").cpu()
@@ -238,7 +238,7 @@ def test_variance_regulariser_backward_vs_oracle():
     assert abs(out.loss - ref["loss"]) < 2e-3 * abs(ref["loss"]), (out.loss, ref["loss"])
     for name in ("predictor_proj.weight", "predictor_blocks.1.mlp.fc1.weight", "mask_tokens.0"):
         g = tr.arena.grad("pred." + name).float().cpu().reshape(ref["grads"]["pred"][name].shape)
-        assert rel_l2(g, ref["grads"]["pred"][name]) < 8e-2, (name, rel_l2(g, ref["grads"]["pred"][name]))
+        assert rel_l2(g, ref["grads"]["pred"][name]) < 3e-2, (name, rel_l2(g, ref["grads"]["pred"][name]))
     g = tr.arena.grad("enc.blocks.0.attn.qkv.weight").float().cpu()
     assert cosine(g, ref["grads"]["enc"]["blocks.0.attn.qkv.weight"]) > 0.995
 
@@ -326,7 +326,7 @@ def _big_model_step_vs_oracle(m, B, n_grad_checks=True):
 def test_vit_large_step_vs_oracle_baseline_shape():
     """BASELINE configs[1] model and clip shape (ViT-L/16, 16x224x224, vitl16.yaml masks), B=2, first step vs the fp32
     oracle: loss <= 1e-3 relative (north-star), targets / context features / predictions rel-L2 <= 2e-2, ten gradients
-    (patch embed, first / middle / last encoder blocks, norms, predictor qkv / fc1 / embed, mask token) rel-L2 <= 8e-2."""
+    (patch embed, first / middle / last encoder blocks, norms, predictor qkv / fc1 / embed, mask token) rel-L2 <= 3e-2."""
     from tests.step_util import VITL
     rep = _big_model_step_vs_oracle(VITL, 2)
     assert rep["loss_rel"] < 1e-3, rep
@@ -334,7 +334,7 @@ def test_vit_large_step_vs_oracle_baseline_shape():
         if k[0] in "hz":
             assert v < 2e-2, (k, v)
         if k.startswith("g:"):
-            assert v < 8e-2, (k, v)
+            assert v < 3e-2, (k, v)
 
 
 def test_vit_huge_step_vs_oracle_head_dim_80():
@@ -347,7 +347,7 @@ def test_vit_huge_step_vs_oracle_head_dim_80():
         if k[0] in "hz":
             assert v < 2e-2, (k, v)
         if k.startswith("g:"):
-            assert v < 8e-2, (k, v)
+            assert v < 3e-2, (k, v)
 
 
 @pytest.mark.timeout(1500)
