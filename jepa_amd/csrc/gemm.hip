@@ -264,6 +264,7 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
 //                   3 = 256x256 staggered 8-phase schedule, gemm8.hip)
 int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);  // gemm8.hip
 int vj_gemm_launch_4w(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);      // gemm4w.hip
+int vj_gemm_launch_8phase_persist(const GemmArgs& a, int epilogue, hipStream_t stream);                        // gemm8p.hip (-100: n/a)
 
 template <int EPI>
 static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
@@ -295,7 +296,15 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
   if (pipe == 0) pipe = 1;       // BK64 double buffer (beats the BK32 ring on every step shape)
   if (a.K % 64 != 0) pipe = 2;   // K % 32 only fits the BK32 pipeline
   if (cfg == 3) pipe = 2;
-  if (pipe == 3 && a.K % 64 == 0 && !reg_staged) return vj_gemm_launch_8phase(a, EPI, ws, ws_bytes, stream);
+  if (pipe == 3 && a.K % 64 == 0 && !reg_staged) {
+    // persistent variant (gemm8p.hip): one workgroup per CU walks its tiles, next tile's operands prefetched under the
+    // current tile, epilogue stores drained under the next K loop; bit-identical outputs.  Run-time option "gemm_persist".
+    if (EPI != EPI_F32 && vj_opt(VJ_OPT_GEMM_PERSIST) != 0 && a.dbg < 2) {
+      const int rc = vj_gemm_launch_8phase_persist(a, EPI, stream);
+      if (rc != -100) return rc;
+    }
+    return vj_gemm_launch_8phase(a, EPI, ws, ws_bytes, stream);
+  }
   if (pipe == 3) pipe = 1;
   if (reg_staged) {
     if (a.K % 64 != 0) return launch_gemm<32, 2, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream);

@@ -8,6 +8,8 @@
 //   reg_fn : sqrt(var_tokens(z)+1e-4)                    app/vjepa/train.py:448-449,458
 #include "common.hpp"
 
+int vj_reduce_partials_pair(const float* part, float* out_a, float* out_b, int64_t P, int64_t D, float alpha, float beta,
+                            hipStream_t stream);   // rows.hip
 int vj_reduce_partials_strided(const float* part, float* out, int64_t P, int64_t N, int64_t stride, float alpha,
                                float beta, hipStream_t stream);
 
@@ -218,9 +220,7 @@ extern "C" int vj_layernorm_bwd(const void* dy_bf16, const void* x_bf16, const f
   else VJ_LNB(4);
 #undef VJ_LNB
   VJ_LAUNCH_CHECK("vj_layernorm_bwd");
-  int rc = vj_reduce_partials_strided((const float*)ws, dgamma, nb, D, 2 * D, alpha, beta_acc, stream);
-  if (rc) return rc;
-  return vj_reduce_partials_strided((const float*)ws + D, dbeta, nb, D, 2 * D, alpha, beta_acc, stream);
+  return vj_reduce_partials_pair((const float*)ws, dgamma, dbeta, nb, D, alpha, beta_acc, stream);   // one launch for both
 }
 
 // ---------------------------------------------------------------------------------------------

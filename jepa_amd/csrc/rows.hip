@@ -355,10 +355,11 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 
 // out[n] = alpha * sum_p part[p*stride + n] + (beta != 0 ? beta * out[n] : 0)
 // one workgroup per 64 columns, 8 partial-lanes of 64 threads each (coalesced 256-B row reads, 8 in flight),
-// then a fixed-order LDS combine -> deterministic.
+// then a fixed-order LDS combine -> deterministic.  Columns n >= split go to out2[n - split] (two outputs from one
+// partial matrix in ONE launch: LayerNorm's dgamma | dbeta); split must be a multiple of 64.
 __global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int64_t P, int64_t N, int64_t stride, float alpha,
-                                                              float beta) {
+                                                              float* __restrict__ out2, int64_t split, int64_t P,
+                                                              int64_t N, int64_t stride, float alpha, float beta) {
   __shared__ float red[8][64];
   const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int64_t n = (int64_t)blockIdx.x * 64 + c;
@@ -374,17 +375,33 @@ __global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __res
 #pragma unroll
     for (int i = 1; i < 8; i++) t += red[i][c];
     t *= alpha;
-    if (beta != 0.f) t += beta * out[n];
-    out[n] = t;
+    float* o = n < split ? out + n : out2 + (n - split);
+    if (beta != 0.f) t += beta * *o;
+    *o = t;
   }
 }
 
 int vj_reduce_partials_strided(const float* part, float* out, int64_t P, int64_t N, int64_t stride, float alpha,
                                float beta, hipStream_t stream) {
   if (N == 0) return 0;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(512), 0, stream, part, out, P, N,
-                     stride, alpha, beta);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(512), 0, stream, part, out,
+                     (float*)nullptr, N, P, N, stride, alpha, beta);
   VJ_LAUNCH_CHECK("vj_reduce_partials");
+  return 0;
+}
+
+// part[p][0:D] -> out_a, part[p][D:2D] -> out_b in one launch (D % 64 == 0; otherwise two launches)
+int vj_reduce_partials_pair(const float* part, float* out_a, float* out_b, int64_t P, int64_t D, float alpha, float beta,
+                            hipStream_t stream) {
+  if (D == 0) return 0;
+  if (D % 64 != 0) {
+    int rc = vj_reduce_partials_strided(part, out_a, P, D, 2 * D, alpha, beta, stream);
+    if (rc) return rc;
+    return vj_reduce_partials_strided(part + D, out_b, P, D, 2 * D, alpha, beta, stream);
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(2 * D, 64)), dim3(512), 0, stream, part, out_a, out_b, D,
+                     P, 2 * D, 2 * D, alpha, beta);
+  VJ_LAUNCH_CHECK("vj_reduce_partials(pair)");
   return 0;
 }
 

@@ -60,3 +60,66 @@ def test_runtime_options_round_trip_and_unknown_name():
         set_option("gemm_4w", old)
     with pytest.raises(HipKernelError):
         get_option("no_such_option")
+
+
+# ------------------------------------------------------------------------------------------------ persistent GEMM
+def _gemm_case(M, N, K, epi, with_res, with_aux_out, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16) if with_res else None
+    aux_in = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16) if epi == 2 else None
+    return A, W, bias, res, aux_in
+
+
+def _run_gemm(A, W, bias, res, aux_in, epi, with_aux_out):
+    from jepa_amd.hip import ops
+    M, N = A.shape[0], W.shape[0]
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    aux_out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16) if with_aux_out else None
+    ops.gemm_nt(A, W, out=out, bias=None if epi == 2 else bias, residual=res, aux_in=aux_in, aux_out=aux_out, epilogue=epi)
+    return out, aux_out
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("M,N,K", [
+    (8192 + 77, 2304, 512),      # M edge (shifted last row tile), even K-tile count
+    (8192, 2304 + 128, 320),     # N edge (shifted last column tile), ODD K-tile count: the ring half alternates per tile
+    (37632, 1024, 256),          # the minimum K (HEAD and TAIL K-tiles back to back), 588 tiles
+    (10560, 3072, 1088),         # a context-encoder row count of the step, 17 K-tiles
+    (58560, 384, 1536),          # predictor fc2 shape: N = 1.5 tiles
+])
+def test_persistent_gemm_is_bit_identical_to_the_one_tile_kernel(M, N, K):
+    """gemm8p.hip (one workgroup per CU walks its tiles, cross-tile prefetch, shifted edge tiles) must reproduce
+    gemm8.hip bit for bit on every epilogue -- same K order, same epilogue arithmetic -- and both must sit within bf16
+    rounding of an fp32 reference (rel-L2 <= 4e-3).  Three different operand draws per case (race screen)."""
+    from jepa_amd.hip.lib import set_option
+    cases = [(0, False, False), (0, True, False), (1, False, False), (1, False, True), (2, False, False)]
+    for epi, with_res, with_aux in cases:
+        for seed in range(3):
+            ops_in = _gemm_case(M, N, K, epi, with_res, with_aux, 100 * epi + seed)
+            old = set_option("gemm_persist", 0)
+            try:
+                ref, ref_aux = _run_gemm(*ops_in, epi, with_aux)
+                set_option("gemm_persist", 1)
+                got, got_aux = _run_gemm(*ops_in, epi, with_aux)
+            finally:
+                set_option("gemm_persist", old)
+            torch.cuda.synchronize()
+            assert not torch.isnan(got.float()).any(), (epi, with_res, with_aux, seed, "unwritten output")
+            assert torch.equal(got, ref), (epi, with_res, with_aux, seed, int((got != ref).sum()))
+            if with_aux:
+                assert torch.equal(got_aux, ref_aux), (epi, seed, "aux")
+        A, W, bias, res, aux_in = ops_in
+        y = A.float() @ W.float().t()
+        if epi != 2:
+            y = y + bias
+        if epi == 1:
+            y = torch.nn.functional.gelu(y.to(torch.bfloat16).float())
+        if epi == 2:
+            u = aux_in.float()
+            y = y * (0.5 * (1 + torch.erf(u / 2 ** 0.5)) + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5)
+        if res is not None:
+            y = y + res.float()
+        assert rel_l2(got.float().cpu(), y.cpu()) < 4e-3, (epi, rel_l2(got.float().cpu(), y.cpu()))

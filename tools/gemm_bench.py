@@ -13,27 +13,31 @@ from jepa_amd.hip import ops  # noqa: E402
 SHAPES = [  # (tag, M, N, K, epilogue)
     ("tgt qkv", 37632, 3072, 1024, 0), ("tgt proj", 37632, 1024, 1024, 0), ("tgt fc1", 37632, 4096, 1024, 1),
     ("tgt fc2", 37632, 1024, 4096, 0), ("tgt patch", 37632, 1024, 1536, 0),
-    ("ctx qkv", 11392, 3072, 1024, 0), ("ctx proj", 11392, 1024, 1024, 0), ("ctx fc1", 11392, 4096, 1024, 1),
-    ("ctx fc2", 11392, 1024, 4096, 0), ("ctx dfc2", 11392, 4096, 1024, 2), ("ctx dqkv", 11392, 1024, 3072, 0),
-    ("prd qkv", 27848, 1152, 384, 0), ("prd proj", 27848, 384, 384, 0), ("prd fc1", 27848, 1536, 384, 1),
-    ("prd fc2", 27848, 384, 1536, 0), ("prd dqkv", 27848, 384, 1152, 0),
-    ("wg qkv", 3072, 1024, 11392, 3), ("wg proj", 1024, 1024, 11392, 3), ("wg fc1", 4096, 1024, 11392, 3),
-    ("wg fc2", 1024, 4096, 11392, 3), ("wg p.qkv", 1152, 384, 27904, 3), ("wg p.proj", 384, 384, 27904, 3),
+    ("ctx qkv", 10560, 3072, 1024, 0), ("ctx proj", 10560, 1024, 1024, 0), ("ctx fc1", 10560, 4096, 1024, 1),
+    ("ctx fc2", 10560, 1024, 4096, 0), ("ctx dfc2", 10560, 4096, 1024, 2), ("ctx dqkv", 10560, 1024, 3072, 0),
+    ("prd qkv", 55680, 1152, 384, 0), ("prd proj", 55680, 384, 384, 0), ("prd fc1", 55680, 1536, 384, 1),
+    ("prd fc2", 55680, 384, 1536, 0), ("prd dqkv", 55680, 384, 1152, 0),
+    ("wg qkv", 3072, 1024, 10560, 3), ("wg proj", 1024, 1024, 10560, 3), ("wg fc1", 4096, 1024, 10560, 3),
+    ("wg fc2", 1024, 4096, 10560, 3), ("wg p.qkv", 1152, 384, 27904, 3), ("wg p.proj", 384, 384, 27904, 3),
     ("wg p.fc1", 1536, 384, 27904, 3), ("wg p.fc2", 384, 1536, 27904, 3),
     ("sq 4096", 4096, 4096, 4096, 0), ("sq 8192", 8192, 8192, 8192, 0),
 ]
+STEP_SHAPES = [s for s in SHAPES if not s[0].startswith("wg")]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cfgs", default="1.1,2.1,2.3", help="tile.pipeline pairs (see gemm.hip dispatch_gemm)")
+    ap.add_argument("--no-wgrad", action="store_true", help="skip the split-K weight-gradient shapes")
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
-    cfgs = [tuple(int(v) for v in c.split(".")) for c in args.cfgs.split(",")]   # "4.0" = flags 0x100 (gemm4w.hip)
+    from jepa_amd.hip.lib import set_option
+    # "4.0" = flags 0x100 (gemm4w.hip); "8.0" = automatic selection with the persistent 8-phase kernel (gemm8p.hip) enabled
+    cfgs = [tuple(int(v) for v in c.split(".")) for c in args.cfgs.split(",")]
     print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " + " ".join(f"t{c}p{q}(TF/s)" for c, q in cfgs))
-    for tag, M, N, K, epi in SHAPES:
+    for tag, M, N, K, epi in (STEP_SHAPES if args.no_wgrad else SHAPES):
         A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
         B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
         bias = torch.randn(N, device=dev, generator=g)
@@ -41,7 +45,8 @@ def main():
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
         res = []
         for c, q in cfgs:
-            flags = 0x100 if c == 4 else (c << 4) | (q << 6)
+            flags = 0x100 if c == 4 else (0 if c == 8 else (c << 4) | (q << 6))
+            set_option("gemm_persist", 1 if c == 8 else 0)
 
             def run():
                 if epi == 3:

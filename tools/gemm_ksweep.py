@@ -13,12 +13,16 @@ def main():
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     from jepa_amd.hip.lib import set_option
-    for M, N, dbg in ((37632, 3072, 0), (37632, 3072, 1), (37632, 1024, 0), (37632, 1024, 1), (256 * 256, 256, 0)):
+    import itertools
+    shapes = ((37632, 3072), (37632, 1024), (55680, 1536))
+    for (M, N), persist, dbg in itertools.product(shapes, (0, 1), (0, 1)):
         set_option("gemm_dbg", dbg)
-        print(f"--- M={M} N={N} " + ("WITHOUT the epilogue (gemm_dbg=1)" if dbg else "full kernel"))
+        set_option("gemm_persist", persist)
+        print(f"--- M={M} N={N} " + ("persistent kernel (gemm8p.hip)" if persist else "one tile per workgroup (gemm8.hip)") +
+              (", WITHOUT the epilogue (gemm_dbg=1)" if dbg else ""))
         rounds = -(-((M + 255) // 256 * ((N + 255) // 256)) // 256)
         pts = []
-        for K in (128, 256, 512, 1024, 2048, 4096):
+        for K in (256, 384, 512, 1024, 2048, 4096):
             A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
             B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
             bias = torch.randn(N, device=dev, generator=g)
