@@ -421,30 +421,6 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
 }
 
 // =============================================================================================================
-// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]     (softmax-backward row term)
-// =============================================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int64_t B, int S, int H, int hd) {
-  const int64_t total = B * S * H;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int h = (int)(i % H);
-    const int64_t bs = i / H;
-    const int s = (int)(bs % S);
-    const int64_t b = bs / S;
-    const bf16_t* op = o + i * hd;
-    const bf16_t* dp = dout + i * hd;
-    float acc = 0.f;
-    for (int d = 0; d < hd; d += 8) {
-      const u32x4_t a = *(const u32x4_t*)(op + d);
-      const u32x4_t c = *(const u32x4_t*)(dp + d);
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc += bf_lo(a[j]) * bf_lo(c[j]) + bf_hi(a[j]) * bf_hi(c[j]);
-    }
-    delta[(b * H + h) * S + s] = acc;
-  }
-}
-
-// =============================================================================================================
 // backward, part 1: dK, dV.  One workgroup per 64-key block (16 keys per wave), loop over 64-query tiles.
 //   S = Q K^T (lane: S[q = qt*16+4g+r][key = li]),  P = exp2(S*sc - lse2[q]),  dP = dO V^T,
 //   dS = P (dP - delta[q]),  dV^T += dO^T P,  dK^T += Q^T dS  (then * scale)
@@ -605,11 +581,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 //   S^T = K Q^T, dP^T = V dO^T (lane: [key = kt*16+4g+r][q = li]),  dS^T = P^T (dP^T - delta[q]),
 //   dQ^T += K^T dS^T  (then * scale)
 // =============================================================================================================
+//   delta[q] = sum_d dO[q,d] O[q,d] (the softmax-backward row term) is computed HERE, from the dO fragments the wave holds
+//   anyway plus one read of its O rows, and written to `delta` for the dK/dV kernel, which is launched after this one:
+//   the separate delta pass (one more kernel on the critical path of every attention backward) is gone.
 template <int HDP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
+                                                          const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse2,
-                                                          const float* __restrict__ delta,
+                                                          float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
                                                           float sc, float scale, int nqb) {
   // {K,V} x NBUF ring filled by LDS-DMA (see the forward kernel): one barrier per tile, tile t+DIST in flight
@@ -628,6 +608,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bf16_t* kbase = qbase + (int64_t)H * hd;
   const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
   const bf16_t* dobase = dout + (int64_t)b * S * os + (int64_t)h * hd;
+  const bf16_t* obase = o + (int64_t)b * S * os + (int64_t)h * hd;
   const int q0 = qb * 128 + w * 32;
 
   bf16x8_t qf[2][KS], dof[2][KS];
@@ -635,14 +616,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
   for (int qt = 0; qt < 2; qt++) {
     const int q = q0 + qt * 16 + li;
+    float dsum = 0.f;   // this lane's share of delta[q]: head-dim chunks 8g .. 8g+7 of every 32-wide step
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
       const int d0 = ks * 32 + 8 * g;
-      qf[qt][ks] = load_frag_global(qbase + (int64_t)q * rs + d0, q < S && d0 < hd);
-      dof[qt][ks] = load_frag_global(dobase + (int64_t)q * os + d0, q < S && d0 < hd);
+      const bool ok = q < S && d0 < hd;
+      qf[qt][ks] = load_frag_global(qbase + (int64_t)q * rs + d0, ok);
+      dof[qt][ks] = load_frag_global(dobase + (int64_t)q * os + d0, ok);
+      const u32x4_t ov = __builtin_bit_cast(u32x4_t, load_frag_global(obase + (int64_t)q * os + d0, ok));
+      const u32x4_t dv = __builtin_bit_cast(u32x4_t, dof[qt][ks]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) dsum += bf_lo(ov[j]) * bf_lo(dv[j]) + bf_hi(ov[j]) * bf_hi(dv[j]);
     }
+    dsum += __shfl_xor(dsum, 16, 64);   // the four lane groups g hold the four 8-element chunks of a step
+    dsum += __shfl_xor(dsum, 32, 64);
     lse_q[qt] = q < S ? lse2[((int64_t)b * H + h) * S + q] : INFINITY;
-    dl_q[qt] = q < S ? delta[((int64_t)b * H + h) * S + q] : 0.f;
+    dl_q[qt] = q < S ? dsum : 0.f;
+    if (g == 0 && q < S) delta[((int64_t)b * H + h) * S + q] = dsum;
   }
   f32x4_t dqacc[2][DT];
 #pragma unroll
@@ -822,24 +812,18 @@ extern "C" int vj_attn_bwd(const void* qkv, const void* o, const void* dout, con
   VJ_CHECK_ARG(ws_bytes >= vj_attn_bwd_ws_bytes(B, S, H), "vj_attn_bwd: workspace too small");
   if (B * S == 0) return 0;
   float* delta = (float*)ws;
-  {
-    int64_t gsz = cdiv64(B * S * H, 256);
-    if (gsz > 256 * 16) gsz = 256 * 16;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)gsz), dim3(256), 0, stream, (const bf16_t*)o,
-                       (const bf16_t*)dout, delta, B, (int)S, (int)H, (int)hd);
-    VJ_LAUNCH_CHECK("vj_attn_bwd(delta)");
-  }
   const int nkb = (int)cdiv64(S, 64), nqb = (int)cdiv64(S, 128);
   const int64_t g1 = B * H * nkb, g2 = B * H * nqb;
   VJ_CHECK_ARG(g1 < (1ll << 31), "vj_attn_bwd: grid too large");
   const float sc = scale * LOG2E;
+  // dQ first: it also produces delta[b,h,s] = dO . O for the dK/dV kernel behind it on the same stream
 #define VJ_BWD_LAUNCH(HDPV)                                                                                        \
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<HDPV>, dim3((unsigned)g2), dim3(256), 0, stream, (const bf16_t*)qkv,       \
+                     (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H,     \
+                     (int)hd, sc, scale, nqb);                                                                     \
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HDPV>, dim3((unsigned)g1), dim3(256), 0, stream, (const bf16_t*)qkv,     \
                      (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H, (int)hd, sc, scale,   \
-                     nkb);                                                                                         \
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<HDPV>, dim3((unsigned)g2), dim3(256), 0, stream, (const bf16_t*)qkv,       \
-                     (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H, (int)hd, sc, scale,   \
-                     nqb);
+                     nkb);
   switch (pick_hdp(hd)) {
     case 32: VJ_BWD_LAUNCH(32); break;
     case 64: VJ_BWD_LAUNCH(64); break;

@@ -392,7 +392,19 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   b.ws = nullptr;
   b.ktiles_per = (int)(a.K / 64);
   const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
-  const int grid = tiles < g_num_cus ? (int)tiles : g_num_cus;
+  // Grid: the tile count is fixed, so the kernel takes `rounds` = ceil(tiles / CUs) tile times whatever the grid is; the
+  // SMALLEST grid that still needs only `rounds` tiles per workgroup leaves the other CUs to the step's second stream for
+  // the whole launch instead of idling them in a ragged last round (588 tiles: 200 workgroups x 3 tiles, 56 CUs free,
+  // rather than 256 workgroups of which 180 run a third tile).  Equal workgroup counts per XCD keep the bands balanced.
+  // Option gemm_persist = 2 launches one workgroup per CU regardless (A/B).
+  int grid = g_num_cus;
+  if (vj_opt(VJ_OPT_GEMM_PERSIST) != 2) {
+    const int64_t rounds = cdiv64(tiles, g_num_cus);
+    const int64_t band = cdiv64(tiles, 8);                  // tiles of the largest XCD band
+    int64_t per_xcd = cdiv64(band, rounds);
+    if (per_xcd * 8 > g_num_cus) per_xcd = g_num_cus / 8;
+    grid = (int)(per_xcd * 8);
+  }
   hipLaunchKernelGGL(gemm_nt_8phase_persist_kernel<EPI>, dim3(grid), dim3(512), smem, stream, b);
   VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase)");
   return 0;
