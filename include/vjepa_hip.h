@@ -65,6 +65,14 @@ int vj_layernorm_bwd(const void* dy_bf16, const void* x_bf16, const float* gamma
                      float alpha, float beta_acc, int64_t rows, int64_t D, void* ws, int64_t ws_bytes,
                      vj_stream_t stream);
 
+/* the same, plus dxsum[D] (nullable) = alpha * column sums of dx + beta_acc * old: in a Block, dx of norm2's backward is the dY
+ * of attn.proj and dx of norm1's backward the dY of the previous block's mlp.fc2, so autograd's bias gradients of those two
+ * Linears (sum over tokens of dY, modules.py:34,76) come out of this pass instead of a separate read of dY. */
+int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
+                            const float* rstd, const void* dres_bf16, void* dx_bf16, float* dgamma, float* dbeta,
+                            float* dxsum, float alpha, float beta_acc, int64_t rows, int64_t D, void* ws,
+                            int64_t ws_bytes, vj_stream_t stream);
+
 /* ---- bf16 MFMA GEMM  C[M,N] = A[M,K] * B[N,K]^T (+ fused epilogue) ------------------------------------------
  * nn.Linear fwd/bwd (modules.py:31-34,63,76; predictor.py:194,237) and the Conv3d GEMM (patch_embed.py:56).
  * epilogue: 0 bf16 out = acc [+bias] [+residual]      (qkv / proj+residual / fc2+residual / dgrads)

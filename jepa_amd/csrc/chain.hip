@@ -324,7 +324,9 @@ struct SideCtx {
 };
 
 // dW (fp32, += beta*old) = alpha * dy^T x_in ; db = alpha * colsum(dy) -- on the side stream, after `main` produced dy
-static int wgrad(const SideCtx& c, const void* dy, const void* x_in, const vj_linear_t& lw, int lane = 0) {
+static int wgrad(const SideCtx& c, const void* dy, const void* x_in, const vj_linear_t& lw_in, int lane = 0, bool bias_done = false) {
+  vj_linear_t lw = lw_in;
+  if (bias_done) lw.gb = nullptr;   // the bias gradient (column sum of dy) came out of the LayerNorm backward that produced dy
   const int64_t M = c.M, Mp = pad64i(M), N = lw.n_out, K = lw.k_in;
   if (lane == 1 && c.side2 == nullptr) lane = 0;
   hipStream_t st = lane == 1 ? c.side2 : c.side;
@@ -389,15 +391,19 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     // the buffers this block is about to overwrite were last read by the weight gradients of block li+2
     if (sc.side != sc.main && li + 2 < n_blocks) HIPCH(hipStreamWaitEvent(stream, side_done[li + 2], 0), "vj_blocks_bwd");
     // fc2: dgrad fused with GELU' ; wgrad reads (dx2, g)
-    CH(wgrad(sc, dx2, w + F.g, b.fc2));
+    // dx2 of every block but the last is the dx of block li+1's norm1 backward, which also produced its column sums
+    const bool fuse_cs = sc.tn != 0;   // (the NT route folds the bias gradient into its dY transpose instead)
+    CH(wgrad(sc, dx2, w + F.g, b.fc2, 0, fuse_cs && li + 1 < n_blocks));
     CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream, g_dgrad_flags));
     // fc1
     CH(wgrad(sc, du, w + F.y2, b.fc1, 1));
     CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
-    CH(vj_layernorm_bwd(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
-                        dx1, b.norm2.gg, b.norm2.gb, alpha, beta_acc, M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    // dx1 is the dY of proj: its bias gradient = column sums of dx1, produced by this pass
+    CH(vj_layernorm_bwd_colsum(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
+                               dx1, b.norm2.gg, b.norm2.gb, fuse_cs ? b.proj.gb : nullptr, alpha, beta_acc, M, D,
+                               tmp + L.ln_ws, L.ln_ws_bytes, stream));
     // proj
-    CH(wgrad(sc, dx1, w + F.o, b.proj));
+    CH(wgrad(sc, dx1, w + F.o, b.proj, 0, fuse_cs));
     CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     for (int64_t s = 0; s < n_segs; s++) {
       const vj_seg_t& sg = segs[s];
@@ -411,8 +417,10 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     CH(wgrad(sc, dqkv, w + F.y1, b.qkv, 1));
     CH(gemm(dqkv, 3 * D, b.qkv.wT, b.qkv.ldwT, tmp + L.dy1, D, M, D, 3 * D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0,
             stream, g_dgrad_flags));
-    CH(vj_layernorm_bwd(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
-                        b.norm1.gg, b.norm1.gb, alpha, beta_acc, M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    // dx is the dY of the previous block's fc2 (its dx2): that bias gradient comes out of this pass
+    CH(vj_layernorm_bwd_colsum(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
+                               b.norm1.gg, b.norm1.gb, (fuse_cs && li > 0) ? blocks[li - 1].fc2.gb : nullptr, alpha, beta_acc,
+                               M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
     if (sc.side2) CH(stream_after(sc.side, sc.side2, "vj_blocks_bwd(lane join)"));
     if (sc.side != sc.main) {
       hipEvent_t e = next_event();

@@ -188,6 +188,10 @@ __device__ __forceinline__ void gemm8_body(const GemmArgs& p, char* smem, int tm
       const int q = 4 * t + ph;
       const char* slot = smem + (q & 7) * PART_BYTES;
       // ---------------- L(q)
+#ifdef VJ_GEMM8_SKIP_READS   // timing experiment (A/B build `python -m jepa_amd.build skipreads -DVJ_GEMM8_SKIP_READS`): after the
+      if (t > 0) {          // first K-tile the fragment reads are skipped -- WRONG results, same MFMA operands forever -- which
+      } else                // bounds what moving the LDS reads out of the load sections could buy
+#endif
       if (ph == 0) {
 #pragma unroll
         for (int j = 0; j < 2; j++)

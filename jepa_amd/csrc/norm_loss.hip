@@ -8,8 +8,8 @@
 //   reg_fn : sqrt(var_tokens(z)+1e-4)                    app/vjepa/train.py:448-449,458
 #include "common.hpp"
 
-int vj_reduce_partials_pair(const float* part, float* out_a, float* out_b, int64_t P, int64_t D, float alpha, float beta,
-                            hipStream_t stream);   // rows.hip
+int vj_reduce_partials_multi(const float* part, float* const* outs, int nseg, int64_t P, int64_t D, float alpha, float beta,
+                             hipStream_t stream);   // rows.hip
 int vj_reduce_partials_strided(const float* part, float* out, int64_t P, int64_t N, int64_t stride, float alpha,
                                float beta, hipStream_t stream);
 
@@ -109,25 +109,31 @@ extern "C" int vj_layernorm_fwd(const void* x_bf16, const float* gamma, const fl
 // ---------------------------------------------------------------------------------------------
 // layernorm_bwd: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres], g = dy*gamma
 // per-block partial dgamma/dbeta in fp32 -> part[blk][0:D]=dgamma, part[blk][D:2D]=dbeta
+// CS: also the column sums of the OUTPUT dx (fp32, before the bf16 rounding) -> part[blk][2D:3D].  In a transformer block
+// dx of norm2's backward is the dY of the proj Linear and dx of norm1's backward is the dY of the previous block's fc2, so
+// their bias gradients (colsum of dY) come out of this pass for 16 more accumulator registers instead of costing a
+// separate read of dY each (the transpose-free weight-gradient route has no transpose pass to fold them into).
 // ---------------------------------------------------------------------------------------------
 #define LN_BWD_MAX_BLOCKS 1024
-template <int NCH>
+template <int NCH, bool CS>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in,
                                                             const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
                                                             float* __restrict__ part, int64_t rows, int D) {
-  __shared__ float red[4][1024];  // 4 waves x (512 dgamma | 512 dbeta) staged per chunk pass
+  constexpr int NSEG = CS ? 3 : 2;
+  __shared__ float red[4][512 * NSEG];  // 4 waves x (512 dgamma | 512 dbeta [| 512 colsum dx]) staged per chunk pass
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float invD = 1.0f / (float)D;
-  float ag[NCH][8], ab[NCH][8], gam[NCH][8];
+  float ag[NCH][8], ab[NCH][8], gam[NCH][8], as[CS ? NCH : 1][8];
 #pragma unroll
   for (int i = 0; i < NCH; i++) {
     const int c = lane * 8 + i * 512;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       ag[i][j] = ab[i][j] = 0.f;
+      if constexpr (CS) as[i][j] = 0.f;
       gam[i][j] = (c < D) ? gamma[c + j] : 0.f;
     }
   }
@@ -170,12 +176,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] += rstd * (g[i][j] - c1 - xh[i][j] * c2);
+        if constexpr (CS) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) as[i][j] += o[j];
+        }
         store8(dx + r * D + c, o);
       }
     }
   }
   // cross-wave reduction of the column partials, one chunk pass at a time (512 columns x {dgamma,dbeta})
-  float* pg = part + (int64_t)blockIdx.x * 2 * D;
+  float* pg = part + (int64_t)blockIdx.x * NSEG * D;
 #pragma unroll
   for (int i = 0; i < NCH; i++) {
     if (i * 512 < D) {
@@ -184,9 +194,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
       for (int j = 0; j < 8; j++) {
         red[wv][lane * 8 + j] = ag[i][j];
         red[wv][512 + lane * 8 + j] = ab[i][j];
+        if constexpr (CS) red[wv][1024 + lane * 8 + j] = as[i][j];
       }
       __syncthreads();
-      for (int q = threadIdx.x; q < 1024; q += 256) {
+      for (int q = threadIdx.x; q < 512 * NSEG; q += 256) {
         const int col = (q & 511) + i * 512;
         if (col < D) {
           const float s = red[0][q] + red[1][q] + red[2][q] + red[3][q];
@@ -197,30 +208,46 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   }
 }
 
-extern "C" int64_t vj_layernorm_bwd_ws_bytes(int64_t D) { return (int64_t)LN_BWD_MAX_BLOCKS * 2 * D * 4; }
+extern "C" int64_t vj_layernorm_bwd_ws_bytes(int64_t D) { return (int64_t)LN_BWD_MAX_BLOCKS * 3 * D * 4; }
 
-// dgamma/dbeta: out = alpha * sum + beta_acc * out   (beta_acc = 1 accumulates across calls)
-extern "C" int vj_layernorm_bwd(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
-                                const float* rstd, const void* dres_bf16, void* dx_bf16, float* dgamma, float* dbeta,
-                                float alpha, float beta_acc, int64_t rows, int64_t D, void* ws, int64_t ws_bytes,
-                                hipStream_t stream) {
+// dgamma/dbeta (and dxsum, nullable: column sums of dx) : out = alpha * sum + beta_acc * out   (beta_acc = 1 accumulates)
+extern "C" int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
+                                       const float* rstd, const void* dres_bf16, void* dx_bf16, float* dgamma,
+                                       float* dbeta, float* dxsum, float alpha, float beta_acc, int64_t rows, int64_t D,
+                                       void* ws, int64_t ws_bytes, hipStream_t stream) {
   VJ_CHECK_ARG(D % 8 == 0 && D <= 512 * LN_MAX_CHUNKS, "vj_layernorm_bwd: D=%ld unsupported", (long)D);
   VJ_CHECK_ARG(ws_bytes >= vj_layernorm_bwd_ws_bytes(D), "vj_layernorm_bwd: workspace too small");
   if (rows == 0) return 0;
   int64_t nb = cdiv64(rows, 16);  // >= 16 rows per workgroup so the column partials amortise
   if (nb > LN_BWD_MAX_BLOCKS) nb = LN_BWD_MAX_BLOCKS;
   if (nb < 1) nb = 1;
-#define VJ_LNB(NCHV)                                                                                                \
-  hipLaunchKernelGGL(layernorm_bwd_kernel<NCHV>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16,   \
-                     (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws, \
+#define VJ_LNB(NCHV, CSV)                                                                                               \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NCHV, CSV>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16, \
+                     (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws,    \
                      rows, (int)D)
-  if (D <= 512) VJ_LNB(1);
-  else if (D <= 1024) VJ_LNB(2);
-  else if (D <= 1536) VJ_LNB(3);
-  else VJ_LNB(4);
+  if (dxsum != nullptr) {
+    if (D <= 512) VJ_LNB(1, true);
+    else if (D <= 1024) VJ_LNB(2, true);
+    else if (D <= 1536) VJ_LNB(3, true);
+    else VJ_LNB(4, true);
+  } else {
+    if (D <= 512) VJ_LNB(1, false);
+    else if (D <= 1024) VJ_LNB(2, false);
+    else if (D <= 1536) VJ_LNB(3, false);
+    else VJ_LNB(4, false);
+  }
 #undef VJ_LNB
   VJ_LAUNCH_CHECK("vj_layernorm_bwd");
-  return vj_reduce_partials_pair((const float*)ws, dgamma, dbeta, nb, D, alpha, beta_acc, stream);   // one launch for both
+  float* outs[3] = {dgamma, dbeta, dxsum};
+  return vj_reduce_partials_multi((const float*)ws, outs, dxsum != nullptr ? 3 : 2, nb, D, alpha, beta_acc, stream);   // ONE launch
+}
+
+extern "C" int vj_layernorm_bwd(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
+                                const float* rstd, const void* dres_bf16, void* dx_bf16, float* dgamma, float* dbeta,
+                                float alpha, float beta_acc, int64_t rows, int64_t D, void* ws, int64_t ws_bytes,
+                                hipStream_t stream) {
+  return vj_layernorm_bwd_colsum(dy_bf16, x_bf16, gamma, mean, rstd, dres_bf16, dx_bf16, dgamma, dbeta, nullptr, alpha,
+                                 beta_acc, rows, D, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

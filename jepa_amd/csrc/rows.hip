@@ -317,15 +317,15 @@ extern "C" int vj_transpose_colsum_bf16(const void* in, void* out, int64_t M, in
 // each group of `group` rows -- used both for plain bias grads (group = M) and for the mask-token grad,
 // which sums only the target rows j >= Ke of every [Ke+Kp]-row sample).  Deterministic two-stage sum.
 // ---------------------------------------------------------------------------------------------
-#define VJ_COLSUM_PARTS 64
+#define VJ_COLSUM_PARTS 256   // maximum number of row chunks (workspace sizing); the launcher picks 64 .. 256
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, float* __restrict__ part,
                                                           int64_t M, int64_t N, int64_t ld, int64_t group,
-                                                          int64_t row_lo, int64_t row_hi) {
+                                                          int64_t row_lo, int64_t row_hi, int parts) {
   __shared__ float red[8][256];
   const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;  // 32 column groups of 8, 8 row lanes
   const int64_t n = (int64_t)blockIdx.x * 256 + cg * 8;
   const int64_t p = blockIdx.y;
-  const int64_t rows_per = cdiv64(M, VJ_COLSUM_PARTS);
+  const int64_t rows_per = cdiv64(M, parts);
   const int64_t mbeg = p * rows_per, mend = (mbeg + rows_per < M) ? mbeg + rows_per : M;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (n < N) {
@@ -355,11 +355,15 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 
 // out[n] = alpha * sum_p part[p*stride + n] + (beta != 0 ? beta * out[n] : 0)
 // one workgroup per 64 columns, 8 partial-lanes of 64 threads each (coalesced 256-B row reads, 8 in flight),
-// then a fixed-order LDS combine -> deterministic.  Columns n >= split go to out2[n - split] (two outputs from one
-// partial matrix in ONE launch: LayerNorm's dgamma | dbeta); split must be a multiple of 64.
-__global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              float* __restrict__ out2, int64_t split, int64_t P,
-                                                              int64_t N, int64_t stride, float alpha, float beta) {
+// then a fixed-order LDS combine -> deterministic.  The N columns may be split into up to three segments of `seg`
+// columns with their own outputs (several reductions over one partial matrix in ONE launch: LayerNorm's
+// dgamma | dbeta | column sum of dx); seg must be a multiple of 64.
+struct ReduceOuts {
+  float* o[3];
+};
+__global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __restrict__ part, ReduceOuts outs, int64_t seg,
+                                                              int64_t P, int64_t N, int64_t stride, float alpha,
+                                                              float beta) {
   __shared__ float red[8][64];
   const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int64_t n = (int64_t)blockIdx.x * 64 + c;
@@ -375,7 +379,8 @@ __global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __res
 #pragma unroll
     for (int i = 1; i < 8; i++) t += red[i][c];
     t *= alpha;
-    float* o = n < split ? out + n : out2 + (n - split);
+    const int64_t sg = n / seg;                       // workgroup-uniform (seg % 64 == 0)
+    float* o = (sg == 0 ? outs.o[0] : (sg == 1 ? outs.o[1] : outs.o[2])) + (n - sg * seg);
     if (beta != 0.f) t += beta * *o;
     *o = t;
   }
@@ -384,24 +389,28 @@ __global__ __launch_bounds__(512) void reduce_partials_kernel(const float* __res
 int vj_reduce_partials_strided(const float* part, float* out, int64_t P, int64_t N, int64_t stride, float alpha,
                                float beta, hipStream_t stream) {
   if (N == 0) return 0;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(512), 0, stream, part, out,
-                     (float*)nullptr, N, P, N, stride, alpha, beta);
+  ReduceOuts outs = {{out, nullptr, nullptr}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(N, 64)), dim3(512), 0, stream, part, outs,
+                     (int64_t)(cdiv64(N, 64) * 64), P, N, stride, alpha, beta);
   VJ_LAUNCH_CHECK("vj_reduce_partials");
   return 0;
 }
 
-// part[p][0:D] -> out_a, part[p][D:2D] -> out_b in one launch (D % 64 == 0; otherwise two launches)
-int vj_reduce_partials_pair(const float* part, float* out_a, float* out_b, int64_t P, int64_t D, float alpha, float beta,
-                            hipStream_t stream) {
-  if (D == 0) return 0;
+// part[p][k*D : (k+1)*D] -> outs[k], k < nseg <= 3, in one launch (D % 64 == 0; otherwise one launch per output)
+int vj_reduce_partials_multi(const float* part, float* const* outs, int nseg, int64_t P, int64_t D, float alpha, float beta,
+                             hipStream_t stream) {
+  if (D == 0 || nseg == 0) return 0;
   if (D % 64 != 0) {
-    int rc = vj_reduce_partials_strided(part, out_a, P, D, 2 * D, alpha, beta, stream);
-    if (rc) return rc;
-    return vj_reduce_partials_strided(part + D, out_b, P, D, 2 * D, alpha, beta, stream);
+    for (int k = 0; k < nseg; k++) {
+      int rc = vj_reduce_partials_strided(part + k * D, outs[k], P, D, (int64_t)nseg * D, alpha, beta, stream);
+      if (rc) return rc;
+    }
+    return 0;
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(2 * D, 64)), dim3(512), 0, stream, part, out_a, out_b, D,
-                     P, 2 * D, 2 * D, alpha, beta);
-  VJ_LAUNCH_CHECK("vj_reduce_partials(pair)");
+  ReduceOuts ro = {{outs[0], nseg > 1 ? outs[1] : nullptr, nseg > 2 ? outs[2] : nullptr}};
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv64(nseg * D, 64)), dim3(512), 0, stream, part, ro, D, P,
+                     (int64_t)nseg * D, (int64_t)nseg * D, alpha, beta);
+  VJ_LAUNCH_CHECK("vj_reduce_partials(multi)");
   return 0;
 }
 
@@ -420,11 +429,18 @@ extern "C" int vj_colsum_bf16(const void* in, int64_t M, int64_t N, int64_t ld, 
                (long)vj_colsum_ws_bytes(N));
   if (N == 0) return 0;
   if (group <= 0) group = (M > 0 ? M : 1);
-  dim3 grid((unsigned)cdiv64(N, 256), VJ_COLSUM_PARTS);
+  // row chunks: enough workgroups (>= ~2048, 8 per CU) to keep HBM busy when N is narrow (N = 1024: 4 column groups), at
+  // least 8 rows per row lane and chunk; the chunk count only changes the (fixed, deterministic) summation order
+  const int64_t gx = cdiv64(N, 256);
+  int64_t parts = cdiv64(2048, gx);
+  if (parts < 64) parts = 64;
+  if (parts > VJ_COLSUM_PARTS) parts = VJ_COLSUM_PARTS;
+  while (parts > 64 && M / parts < 64) parts /= 2;
+  dim3 grid((unsigned)gx, (unsigned)parts);
   hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)in, (float*)ws, M, N, ld, group,
-                     row_lo, row_hi);
+                     row_lo, row_hi, (int)parts);
   VJ_LAUNCH_CHECK("vj_colsum_bf16");
-  return vj_reduce_partials((const float*)ws, out, VJ_COLSUM_PARTS, N, alpha, beta, stream);
+  return vj_reduce_partials((const float*)ws, out, parts, N, alpha, beta, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -114,10 +114,11 @@ def _tn_ok(n_out: int, k_in: int) -> bool:
     return _get_option("wgrad_tn") == 1 and n_out % 8 == 0 and k_in % 8 == 0
 
 
-def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0):
+def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0, bias_done: bool = False):
+    """bias_done: the bias gradient (column sums of dy) was produced by the LayerNorm backward that produced dy."""
     acc = beta != 0.0
     if _tn_ok(dy.shape[1], x_in.shape[1]):
-        if lw.gb is not None:
+        if lw.gb is not None and not bias_done:
             ops.colsum(dy, lw.gb, alpha=alpha, accumulate=acc)
         ops.gemm_wgrad_tn(dy, x_in, lw.gw, alpha=alpha, beta=beta)
         return
@@ -126,16 +127,17 @@ def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0):
     ops.gemm_wgrad(dyT, xT, lw.gw, alpha=alpha, beta=beta)
 
 
-def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None, beta: float = 0.0):
+def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None, beta: float = 0.0,
+                     bias_done: bool = False):
     """dW (fp32, into lw.gw) = alpha * dy^T x_in + beta * dW ; db likewise ; returns dx = dy W (bf16).
     The weight-gradient half goes to the side stream; the caller joins before the gradients are consumed."""
     side = side_stream(dy.device)
     if side.enabled:
         side.fork(dy, x_in)
         with torch.cuda.stream(side.stream):
-            _wgrad(dy, x_in, lw, alpha, beta)
+            _wgrad(dy, x_in, lw, alpha, beta, bias_done)
     else:
-        _wgrad(dy, x_in, lw, alpha, beta)
+        _wgrad(dy, x_in, lw, alpha, beta, bias_done)
     if not need_dx:
         return None
     if dgelu_aux is not None:
@@ -143,24 +145,30 @@ def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_au
     return ops.gemm_nt(dy, lw.wT)
 
 
-def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: float, beta: float = 0.0):
+def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: float, beta: float = 0.0,
+                   fc2_bias_done: bool = False, prev_fc2_gb=None):
+    """With transpose-free weight gradients the bias gradients of proj and of the PREVIOUS block's fc2 are the column
+    sums of the two LayerNorm backward outputs and come out of those passes (vj_layernorm_bwd_colsum); `fc2_bias_done`
+    says that this block's fc2 bias gradient was produced that way by the block above.  Same kernels, same order as
+    vj_blocks_bwd (csrc/chain.hip): bit-identical results."""
     x, y1, mean1, rstd1, qkv, o, lses, x1, y2, mean2, rstd2, u, g = saved
     D = x.shape[1]
     hd = D // heads
     scale = hd ** -0.5
     acc = beta != 0.0
-    du = _linear_backward(dx2, g, bw.fc2, alpha, dgelu_aux=u, beta=beta)   # fc2 dgrad fused with GELU'
+    fuse = _tn_ok(8, 8)
+    du = _linear_backward(dx2, g, bw.fc2, alpha, dgelu_aux=u, beta=beta, bias_done=fuse and fc2_bias_done)   # fc2 dgrad fused with GELU'
     dy2 = _linear_backward(du, y2, bw.fc1, alpha, beta=beta)
     dx1 = ops.layernorm_bwd(dy2, x1, bw.norm2.g, mean2, rstd2, bw.norm2.gg, bw.norm2.gb, dres=dx2, alpha=alpha,
-                            accumulate=acc)
-    do = _linear_backward(dx1, o, bw.proj, alpha, beta=beta)
+                            accumulate=acc, dxsum=bw.proj.gb if fuse else None)
+    do = _linear_backward(dx1, o, bw.proj, alpha, beta=beta, bias_done=fuse)
     dqkv = torch.empty_like(qkv)
     for sg, lse in zip(segs, lses):
         ops.attn_bwd(_rows(qkv, sg), _rows(o, sg), _rows(do, sg), lse, sg.B, sg.S, heads, hd, scale,
                      out=_rows(dqkv, sg))
     dy1 = _linear_backward(dqkv, y1, bw.qkv, alpha, beta=beta)
     return ops.layernorm_bwd(dy1, x, bw.norm1.g, mean1, rstd1, bw.norm1.gg, bw.norm1.gb, dres=dx1, alpha=alpha,
-                             accumulate=acc)
+                             accumulate=acc, dxsum=prev_fc2_gb if fuse else None)
 
 
 # =============================================================================================== encoder
@@ -213,8 +221,10 @@ def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_don
                                    (lambda li: on_layer_done("enc", li)) if on_layer_done is not None else None,
                                    beta_acc=beta, tag=ws_tag)
     else:
-        for li in range(len(ew.blocks) - 1, -1, -1):
-            dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha, beta)
+        nb = len(ew.blocks)
+        for li in range(nb - 1, -1, -1):
+            dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha, beta, fc2_bias_done=li + 1 < nb,
+                                prev_fc2_gb=ew.blocks[li - 1].fc2.gb if li > 0 else None)
             saved_blocks[li] = None
             if on_layer_done is not None:
                 on_layer_done("enc", li)      # bucket launch waits on the side stream's event, not on this stream
@@ -284,8 +294,10 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
                                    (lambda li: on_layer_done("pred", li)) if on_layer_done is not None else None,
                                    beta_acc=beta, tag=ws_tag)
     else:
-        for li in range(len(pw.blocks) - 1, -1, -1):
-            dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha, beta)
+        nb = len(pw.blocks)
+        for li in range(nb - 1, -1, -1):
+            dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha, beta, fc2_bias_done=li + 1 < nb,
+                                prev_fc2_gb=pw.blocks[li - 1].fc2.gb if li > 0 else None)
             saved_blocks[li] = None
             if on_layer_done is not None:
                 on_layer_done("pred", li)

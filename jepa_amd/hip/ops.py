@@ -146,16 +146,19 @@ def layernorm_fwd(x, gamma, beta, eps, save_stats=True, out=None, stream=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, alpha=1.0, accumulate=False, stream=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, alpha=1.0, accumulate=False, dxsum=None,
+                  stream=None):
+    """dxsum (optional fp32 [D]): also alpha * column sums of the returned dx (+ old when accumulating) -- the bias
+    gradient of the Linear whose dY this dx is (include/vjepa_hip.h: vj_layernorm_bwd_colsum)."""
     lib = load_library()
     _req(dy, BF16, "dy")
     rows, D = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty_like(x)
     nws = lib.vj_layernorm_bwd_ws_bytes(D)
     ws = Scratch.get(nws, x.device, "ln", stream=stream)
-    check(lib.vj_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
-                               _ptr(dgamma), _ptr(dbeta), alpha, 1.0 if accumulate else 0.0, rows, D, _ptr(ws), nws,
-                               _stream(stream)), "vj_layernorm_bwd")
+    check(lib.vj_layernorm_bwd_colsum(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
+                                      _ptr(dgamma), _ptr(dbeta), _ptr(dxsum), alpha, 1.0 if accumulate else 0.0, rows, D,
+                                      _ptr(ws), nws, _stream(stream)), "vj_layernorm_bwd")
     return dx
 
 

@@ -123,3 +123,37 @@ def test_persistent_gemm_is_bit_identical_to_the_one_tile_kernel(M, N, K):
         if res is not None:
             y = y + res.float()
         assert rel_l2(got.float().cpu(), y.cpu()) < 4e-3, (epi, rel_l2(got.float().cpu(), y.cpu()))
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm backward + column sums
+@pytest.mark.parametrize("rows,D", [(10560, 1024), (5533, 384), (777, 1280), (40, 192)])
+def test_layernorm_bwd_column_sums_of_dx(rows, D):
+    """vj_layernorm_bwd_colsum: dx / dgamma / dbeta bit-identical to the plain backward; dxsum = alpha * column sums of dx
+    (accumulated in fp32 BEFORE the bf16 rounding of dx) within 2e-3 relative of the fp32 sum of the rounded dx, and
+    accumulating (beta = 1) adds to the previous value."""
+    from jepa_amd.hip import ops
+    g = torch.Generator(device=DEV).manual_seed(rows + D)
+    x = torch.randn(rows, D, device=DEV, generator=g).to(torch.bfloat16)
+    dy = torch.randn(rows, D, device=DEV, generator=g).to(torch.bfloat16)
+    dres = torch.randn(rows, D, device=DEV, generator=g).to(torch.bfloat16)
+    gamma = torch.randn(D, device=DEV, generator=g)
+    beta = torch.randn(D, device=DEV, generator=g)
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-6)
+    outs = []
+    for with_cs in (False, True):
+        dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        cs = torch.full((D,), 3.0, device=DEV) if with_cs else None
+        dx = ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, dres=dres, alpha=0.5, dxsum=cs)
+        if with_cs:
+            first = cs.clone()
+            ops.layernorm_bwd(dy, x, gamma, mean, rstd, dg, db, dres=dres, alpha=0.5, accumulate=True, dxsum=cs)
+            assert torch.allclose(cs, 2 * first, rtol=1e-6, atol=1e-6)
+            cs = first
+        outs.append((dx, dg.clone(), db.clone(), cs))
+    assert torch.equal(outs[0][0], outs[1][0])
+    ref = 0.5 * outs[1][0].float().sum(0)
+    err = float((outs[1][3] - ref).norm() / ref.norm())
+    assert err < 2e-3, err
+    # the first call of the with_cs arm ran with beta = 0: dgamma/dbeta equal the plain call's halves after the accumulate
+    assert torch.allclose(outs[1][1], 2 * outs[0][1], rtol=1e-6, atol=1e-5)
+    assert torch.allclose(outs[1][2], 2 * outs[0][2], rtol=1e-6, atol=1e-5)

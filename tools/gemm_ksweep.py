@@ -15,11 +15,15 @@ def main():
     from jepa_amd.hip.lib import set_option
     import itertools
     shapes = ((37632, 3072), (37632, 1024), (55680, 1536))
-    for (M, N), persist, dbg in itertools.product(shapes, (0, 1), (0, 1)):
+    combos = list(itertools.product(shapes, (0, 1), (0, 1)))
+    if os.environ.get("VJ_LIB_VARIANT"):   # A/B builds (e.g. skipreads): only the one-tile kernel on the first shape
+        combos = [(shapes[0], 0, 0), (shapes[0], 0, 1)]
+        print(f"=== library variant {os.environ['VJ_LIB_VARIANT']}")
+    for (M, N), persist, dbg in combos:
         set_option("gemm_dbg", dbg)
         set_option("gemm_persist", persist)
         print(f"--- M={M} N={N} " + ("persistent kernel (gemm8p.hip)" if persist else "one tile per workgroup (gemm8.hip)") +
-              (", WITHOUT the epilogue (gemm_dbg=1)" if dbg else ""))
+              (", WITHOUT the epilogue (gemm_dbg=1)" if dbg & 1 else ""))
         rounds = -(-((M + 255) // 256 * ((N + 255) // 256)) // 256)
         pts = []
         for K in (256, 384, 512, 1024, 2048, 4096):

@@ -7,8 +7,8 @@ import sys
 
 
 def short(name):
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
-    name = name.replace("void ", "")
     return name[:110]
 
 
