@@ -21,6 +21,7 @@
 //     of the transpose reads (it does after the builtin form; see attention.hip).
 //
 // Split-K over the token tiles and the fp32 epilogue are shared with the NT kernels (gemm_common.hpp).
+#include <type_traits>
 #include "gemm_common.hpp"
 
 #define TN_PART_BYTES 16384
@@ -143,24 +144,80 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(GemmArgs p) {
   tl.row0 = tid >> 4;
   tl.sc8 = ((tid & 15) ^ (((tid >> 4) & 7) << 1)) * 8;
 
-  // ---- prologue: parts -1 (A0 of tile 0), 0, 1, 2 in flight; part -1 landed for everyone
+  // Schedule (round 3).  The transpose reads are two 8-byte LDS instructions per fragment -- 16 or 32 per part -- and with
+  // one wave per SIMD issuing them a load section took longer than the 16 MFMAs of the partner group's compute section
+  // (744 vs 1028 TF/s for the NT kernel on the same shape).  Now the fragments of part q+1 are read INSIDE compute
+  // section C(q), two reads behind every one or two MFMAs (an MFMA 16x16x32 occupies the matrix pipe for 16 cycles, the
+  // reads issue underneath), and a load section only issues the LDS-DMA of part q+5 and waits.  Only the B0 fragments
+  // (register set rb0, still in use in C(4t+3)) are read in a load section, L(4t+4).
+  //   L(q): [q = 4t: rb0 <- part q]  issue part q+5;  s_waitcnt until part q+2 has landed (q+3..q+5 in flight);  barrier
+  //   C(q): 16 MFMA (quadrant q & 3)  ||  reads of part q+1 (q & 3 = 0: rb1, 1: ra1, 2: ra0 of the next K-tile, 3: none); barrier
+  // Visibility: the early group reads part q+1 in C(q), while the late group is still in L(q) -- so a part must be complete
+  // one section earlier than in gemm8.hip: L(j) waits for part j+2, and the late group's L(q-1) (which precedes the barrier
+  // that opens the early group's C(q)) has waited for part q+1.  Prefetch distance 5 keeps three parts in flight as before.
+  // Slot reuse: part p+8 is issued in L(p+3), at least two barriers after the last read of part p by either group.
+  auto wait_landed = [&](int q) {   // tail-safe form of "part q+2 has landed": parts q+3 .. min(q+5, last_part) may be in flight
+    const int younger = last_part - (q + 2);
+    if (younger >= 3) tn_wait_vm<6>();
+    else if (younger == 2) tn_wait_vm<4>();
+    else if (younger == 1) tn_wait_vm<2>();
+    else tn_wait_vm<0>();
+  };
+  // 16 MFMAs of one accumulator quadrant with NF fragment loads (two transpose reads each) spread underneath them
+  auto mma_rd = [&](f32x4_t (&acc4)[4][2], const bf16x8_t (&rb)[2][2], const bf16x8_t (&ra)[4][2], auto nf_tag, auto&& load_frag)
+                    __attribute__((always_inline)) {
+    constexpr int NF = decltype(nf_tag)::value;   // 0, 4 (a B set) or 8 (an A set)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[j][ks], ra[i][ks], acc4[i][j], 0, 0, 0);
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int m = ks * 8 + i * 2 + j;
+          if constexpr (NF == 8) {
+            if (m % 2 == 0) load_frag(m / 2);
+          } else if constexpr (NF == 4) {
+            if (m % 4 == 0) load_frag(m / 4);
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+    // pin the interleave: (MFMA x 16/NF, DS read x 2) per fragment -- without it the scheduler hoists all reads to the top
+    if constexpr (NF == 8) {
+#pragma unroll
+      for (int f = 0; f < 8; f++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    } else if constexpr (NF == 4) {
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    }
+  };
+  using NF0 = std::integral_constant<int, 0>;
+  using NF4 = std::integral_constant<int, 4>;
+  using NF8 = std::integral_constant<int, 8>;
+
+  // ---- prologue: parts -1 .. 4 in flight; parts -1, 0, 1 landed for everyone
   tn_issue_part(p, -1, m0, n0, kt0, smem, tl, wave_u);
 #pragma unroll
-  for (int q = 0; q < 3; q++)
+  for (int q = 0; q < 5; q++)
     if (q <= last_part) tn_issue_part(p, q, m0, n0, kt0, smem, tl, wave_u);
-  if (last_part >= 2) tn_wait_vm<6>();
-  else tn_wait_vm<0>();
+  wait_landed(-1);
   tn_bar();
   if (late_group) tn_bar();
   {
-    const char* slot = smem + 7 * TN_PART_BYTES;
+    const char* slot = smem + 7 * TN_PART_BYTES;   // part -1: A0 of K-tile 0
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) ra0[i][ks] = tn_frag(slot + a_off[i] + ks * 32 * 256);
-    if (3 <= last_part) tn_issue_part(p, 3, m0, n0, kt0, smem, tl, wave_u);
-    if (3 <= last_part) tn_wait_vm<6>();
-    else tn_wait_vm<0>();
   }
   tn_bar();
   tn_bar();
@@ -169,75 +226,34 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(GemmArgs p) {
 #pragma unroll
     for (int ph = 0; ph < 4; ph++) {
       const int q = 4 * t + ph;
-      const char* slot = smem + (q & 7) * TN_PART_BYTES;
       // ---------------- L(q)
       if (ph == 0) {
+        const char* slot = smem + (q & 7) * TN_PART_BYTES;
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
           for (int ks = 0; ks < 2; ks++) rb0[j][ks] = tn_frag(slot + b_off[j] + ks * 32 * 256);
-      } else if (ph == 1) {
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int ks = 0; ks < 2; ks++) rb1[j][ks] = tn_frag(slot + b_off[j] + ks * 32 * 256);
-      } else if (ph == 2) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int ks = 0; ks < 2; ks++) ra1[i][ks] = tn_frag(slot + a_off[i] + ks * 32 * 256);
-      } else if (t + 1 < nk) {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int ks = 0; ks < 2; ks++) ra0[i][ks] = tn_frag(slot + a_off[i] + ks * 32 * 256);
       }
-      if (q + 4 <= last_part) {
-        tn_issue_part(p, q + 4, m0, n0, kt0, smem, tl, wave_u);
-        tn_wait_vm<6>();                              // part q+1 landed; q+2..q+4 in flight
+      if (q + 5 <= last_part) {
+        tn_issue_part(p, q + 5, m0, n0, kt0, smem, tl, wave_u);
+        tn_wait_vm<6>();                              // part q+2 landed; q+3..q+5 in flight
       } else {
-        const int younger = last_part - (q + 1);
-        if (younger >= 2) tn_wait_vm<4>();
-        else if (younger == 1) tn_wait_vm<2>();
-        else tn_wait_vm<0>();
+        wait_landed(q);
       }
       tn_bar();
-      // ---------------- C(q): one quadrant x 64 tokens
-      __builtin_amdgcn_s_setprio(1);
+      // ---------------- C(q): one quadrant x 64 tokens, with the reads of part q+1 underneath
+      const char* nslot = smem + ((q + 1) & 7) * TN_PART_BYTES;
       if (ph == 0) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-              acc[0][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb0[j][ks], ra0[i][ks], acc[0][0][i][j], 0, 0, 0);
+        mma_rd(acc[0][0], rb0, ra0, NF4{}, [&](int f) { rb1[f >> 1][f & 1] = tn_frag(nslot + b_off[f >> 1] + (f & 1) * 32 * 256); });
       } else if (ph == 1) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-              acc[0][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb1[j][ks], ra0[i][ks], acc[0][1][i][j], 0, 0, 0);
+        mma_rd(acc[0][1], rb1, ra0, NF8{}, [&](int f) { ra1[f >> 1][f & 1] = tn_frag(nslot + a_off[f >> 1] + (f & 1) * 32 * 256); });
       } else if (ph == 2) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-              acc[1][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb1[j][ks], ra1[i][ks], acc[1][1][i][j], 0, 0, 0);
+        // (in the last K-tile this reads a slot whose part does not exist: stale LDS bytes into registers nobody uses --
+        //  cheaper than a second copy of the MFMA block behind a branch, which costs ~30 spilled VGPRs)
+        mma_rd(acc[1][1], rb1, ra1, NF8{}, [&](int f) { ra0[f >> 1][f & 1] = tn_frag(nslot + a_off[f >> 1] + (f & 1) * 32 * 256); });
       } else {
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-          for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-              acc[1][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb0[j][ks], ra1[i][ks], acc[1][0][i][j], 0, 0, 0);
+        mma_rd(acc[1][0], rb0, ra1, NF0{}, [&](int) {});
       }
-      __builtin_amdgcn_s_setprio(0);
       tn_bar();
     }
   }
