@@ -26,51 +26,25 @@ LN_EPS = 1e-6  # partial(nn.LayerNorm, eps=1e-6), vision_transformer.py:252-281 
 
 
 class SideStream:
-    """Side HIP streams of the step.  `stream` carries the EMA-target forward (the longer branch of the forward phase, so
-    it keeps the priority of the main stream); the weight-gradient GEMMs and their reductions only feed the optimizer and
-    go to `wstream`: the same stream by default, or -- `low_priority_wgrad` (VJ_WGRAD_LOWPRIO=1) -- a separate stream created
-    with the LOWEST queue priority, so that the dispatcher hands freed CUs to the dgrad chain (the critical path of the
-    backward phase) first.  `fork` / `wfork` make a side stream wait for everything enqueued so far on the main stream;
-    `join` makes the main stream wait for both."""
+    """Second HIP stream of the step: the EMA-target forward in the forward phase, the weight-gradient GEMMs (and the
+    reductions feeding the bias gradients) in the backward phase -- work that is off the main chain and fills the CUs its
+    kernels leave idle.  `fork` makes the side stream wait for everything enqueued so far on the main stream; `join` makes
+    the main stream wait for the side stream.  (A separate lowest-priority stream for the weight gradients was measured in
+    round 3: no effect, +0.1 % in 7 of 8 interleaved rounds -- both phases are throughput-bound, not dispatch-order-bound.)"""
 
     def __init__(self, device):
         import os
         self.stream = torch.cuda.Stream(device=device)
         self.enabled = os.environ.get("VJ_NO_OVERLAP", "0") != "1"   # serial mode for per-kernel profiling
-        self.low_priority_wgrad = os.environ.get("VJ_WGRAD_LOWPRIO", "0") == "1"
-        self._wlow = None
-        self._device = device
-
-    @property
-    def wstream(self):
-        if not self.low_priority_wgrad:
-            return self.stream
-        if self._wlow is None:
-            try:
-                lo = torch.cuda.Stream.priority_range()[0]    # least priority (largest number); HIP has three levels
-            except Exception:   # noqa: BLE001
-                lo = 1
-            self._wlow = torch.cuda.Stream(device=self._device, priority=max(lo, 1))
-        return self._wlow
-
-    @staticmethod
-    def _fork(stream, tensors):
-        stream.wait_stream(torch.cuda.current_stream())
-        for t in tensors:          # allocator plumbing: these buffers are read on the side stream
-            if t is not None:
-                t.record_stream(stream)
 
     def fork(self, *tensors):
-        self._fork(self.stream, tensors)
-
-    def wfork(self, *tensors):
-        self._fork(self.wstream, tensors)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        for t in tensors:          # allocator plumbing: these buffers are read on the side stream
+            if t is not None:
+                t.record_stream(self.stream)
 
     def join(self):
-        cur = torch.cuda.current_stream()
-        cur.wait_stream(self.stream)
-        if self._wlow is not None:
-            cur.wait_stream(self._wlow)
+        torch.cuda.current_stream().wait_stream(self.stream)
 
 
 _SIDE = {}
@@ -160,8 +134,8 @@ def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_au
     The weight-gradient half goes to the side stream; the caller joins before the gradients are consumed."""
     side = side_stream(dy.device)
     if side.enabled:
-        side.wfork(dy, x_in)
-        with torch.cuda.stream(side.wstream):
+        side.fork(dy, x_in)
+        with torch.cuda.stream(side.stream):
             _wgrad(dy, x_in, lw, alpha, beta, bias_done)
     else:
         _wgrad(dy, x_in, lw, alpha, beta, bias_done)
@@ -244,7 +218,7 @@ def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_don
     dx = ops.layernorm_bwd(dout, xl, ew.norm.g, mean, rstd, ew.norm.gg, ew.norm.gb, alpha=alpha, accumulate=beta != 0.0)
     if isinstance(saved_blocks, chain.TrunkCtx):
         side = side_stream(dout.device)
-        dx = chain.blocks_backward(dx, saved_blocks, ew, alpha, side.wstream.cuda_stream if side.enabled else None,
+        dx = chain.blocks_backward(dx, saved_blocks, ew, alpha, side.stream.cuda_stream if side.enabled else None,
                                    (lambda li: on_layer_done("enc", li)) if on_layer_done is not None else None,
                                    beta_acc=beta, tag=ws_tag)
     else:
@@ -317,7 +291,7 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
         on_layer_done("pred", len(pw.blocks))
     if isinstance(saved_blocks, chain.TrunkCtx):
         side = side_stream(dzhat.device)
-        dx = chain.blocks_backward(dx, saved_blocks, pw, alpha, side.wstream.cuda_stream if side.enabled else None,
+        dx = chain.blocks_backward(dx, saved_blocks, pw, alpha, side.stream.cuda_stream if side.enabled else None,
                                    (lambda li: on_layer_done("pred", li)) if on_layer_done is not None else None,
                                    beta_acc=beta, tag=ws_tag)
     else:

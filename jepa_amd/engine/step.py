@@ -259,7 +259,7 @@ class Trainer:
             # ---- backward (predictor first, then encoder layers L-1..0); on the last micro-batch the gradient
             #      buckets go out as layers finish
             if last:
-                self.reducer.begin(side.wstream if side.enabled else None)
+                self.reducer.begin(side.stream if side.enabled else None)
             lhook = hook if last else None
             dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=lhook, beta=beta,
                                     ws_tag=self._ws + "bwd_tmp")

@@ -8,8 +8,7 @@ turns: round r runs `--steps` steps of arm 0, then arm 1, ... with a device sync
 per-arm median / min ms per step and the paired per-round delta against arm 0 (median, and how many rounds agree in sign).
 
     python tools/abab.py --arms "base;4w:gemm_4w=1;tn:wgrad_tn=1" --rounds 6 --steps 6
-host-side switches:  no_overlap=1 (single stream), overlap_fwd=0 (target forward on the main stream),
-                     wgrad_lowprio=1 (weight gradients on their own lowest-priority stream)
+host-side switches:  no_overlap=1 (single stream), overlap_fwd=0 (target forward on the main stream)
 """
 import argparse
 import json
@@ -43,7 +42,7 @@ def parse_arms(spec):
     return arms
 
 
-HOST_SWITCHES = ("no_overlap", "overlap_fwd", "wgrad_lowprio")
+HOST_SWITCHES = ("no_overlap", "overlap_fwd")
 
 
 def main():
@@ -78,7 +77,6 @@ def main():
         for k in lib_opts:
             set_option(k, opts.get(k, defaults[k]))
         side.enabled = not opts.get("no_overlap", 0)
-        side.low_priority_wgrad = bool(opts.get("wgrad_lowprio", 0))
         step_mod._OVERLAP_FWD = bool(opts.get("overlap_fwd", 1))
 
     def run_steps(n, first=0):
