@@ -1,0 +1,437 @@
+// Persistent 8-phase bf16 MFMA GEMM, second schedule: the fragment reads ride under the MFMAs.
+//
+// Everything of gemm8p.hip holds (one workgroup per CU walks a tile list, continuous part stream across tiles, epilogue
+// stores drained under the next K loop, shifted edge tiles, bit-identical outputs); what changes is WHERE the LDS
+// fragment reads sit.  In gemm8.hip / gemm8p.hip a load section L(q) reads part q into registers, issues the LDS-DMA
+// of part q+4 and waits, and the partner wave group's 16 MFMAs hide it -- when it is short enough: measured, a load
+// section is LONGER than a compute section (K-loop slope 1.39 us per K-tile against 1.25 with the reads skipped,
+// profiles/r03_abab_round3.md), so the matrix pipe idles ~20 % of every barrier interval.  Here, as in the TN kernel:
+//   L(q): [q = 4t: rb0 <- B0(t)]  issue the DMA of part q+5;  wait until part q+2 has landed;  barrier
+//   C(q): 16 MFMA of quadrant q & 3  ||  ds_read_b128 of part q+1 (rb1 | ra1 | ra0 of the next K-tile | nothing), one read
+//         behind every second / fourth MFMA;  barrier
+// A part must now be complete one section earlier (the early wave group reads part q+1 in C(q) while the late group is
+// still in L(q)): L(j) waits for part j+2, and prefetch distance 5 keeps three parts in flight across the barriers.
+// Part p+8 is issued in L(p+3), two phases after the last read of part p by either group.
+//
+// Tile transitions (h = ring half of a tile's K-tile 0; K-tile t keeps B0, B1, A1 in half h(t) slots 0..2 and A0(t+1) in slot 3):
+//   TAIL0  K-tile nk-2: phases 2, 3 issue the NEXT tile's A0(0), B0(0)
+//   TAIL1  K-tile nk-1: phases 0..3 issue the next tile's B1(0) | A1(0) | A0(1) | B0(1) + B1(1) + A1(1); no ra0 read
+//   epilogue            vmcnt(0): parts -1 .. 6 of the next tile have landed; stores are issued and not waited for
+//   start               barrier(s), ra0 <- A0(0)
+//   HEAD0  K-tile 0: issues only in phases 2, 3 (A0(2), B0(2)); no waits
+//   HEAD1  K-tile 1: phase 0 issues without waiting (part 6 landed before the epilogue), then the steady state: the first
+//          counted wait comes ten sections after the stores were issued
+#include <type_traits>
+#include "gemm_common.hpp"
+#include "options.hpp"
+
+#define PP_PART 16384
+#define PP_RING (8 * PP_PART)
+#define PP_STAGE_PER_WAVE 4096
+
+namespace {
+
+__device__ __forceinline__ void pp_bar() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);   // nothing (MFMA, ds_read, DMA issue) may be scheduled across a section boundary
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+}
+template <int N>
+__device__ __forceinline__ void pp_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ unsigned pp_lds(const char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+// LDS-DMA, SGPR base + 32-bit lane offset form, through inline assembly (the compiler neither counts it nor assumes an LDS write)
+__device__ __forceinline__ void pp_dma(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+
+// the 8 wave-uniform row-group bases of one tile: A rows m0 + j*128 + mq*64, B rows n0 + j*128 + nq*32 (byte pointers at k = 0)
+struct PpBases {
+  const char* a[2][2];   // [mq][j]
+  const char* b[2][2];   // [nq][j]
+};
+__device__ __forceinline__ void pp_make_bases(PpBases& pb, const char* a0, const char* b0, int64_t lda2, int64_t ldb2) {
+#pragma unroll
+  for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      pb.a[sub][j] = a0 + (int64_t)(j * 128 + sub * 64) * lda2;
+      pb.b[sub][j] = b0 + (int64_t)(j * 128 + sub * 32) * ldb2;
+    }
+}
+
+// logical tile index -> shifted tile origin (always a full 256 x 256 tile inside the matrix)
+__device__ __forceinline__ void pp_tile_origin(const GemmArgs& p, int logical, int64_t& m0, int64_t& n0) {
+  int tm, tn;
+  tile_of(logical, p.tiles_m, p.tiles_n, tm, tn);
+  m0 = (int64_t)tm * 256;
+  n0 = (int64_t)tn * 256;
+  m0 = m0 + 256 <= p.M ? m0 : p.M - 256;
+  n0 = n0 + 256 <= p.N ? n0 : p.N - 256;
+}
+
+enum { PP_STEADY = 0, PP_HEAD0, PP_HEAD1, PP_TAIL0, PP_TAIL1 };
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_8phase_persist2_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_u >> 2, wn = wave_u & 3;
+  const bool late_group = wave_u >= 4;        // waves 4-7 run one barrier interval behind waves 0-3
+  const int frow = lane & 15, fg = lane >> 4;
+
+  // ---- this workgroup's tile list: XCD x (= blockIdx & 7, the hardware's round-robin) owns a contiguous band of the
+  //      grouped tile order; its workgroups take the band's tiles round-robin, so the tiles an XCD works on at any time
+  //      are neighbours (8 row tiles x 4 column tiles: shared A / B panels in its L2)
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int qx = ntile >> 3, rx = ntile & 7;
+  const int band0 = xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx;
+  const int band_n = qx + (xcd < rx ? 1 : 0);
+  const int wgs_x = (G - xcd + 7) >> 3;               // workgroups of this launch that sit on XCD `xcd`
+  if (pos >= band_n) return;                          // (only when there are fewer tiles than workgroups)
+  const int my_tiles = (band_n - pos + wgs_x - 1) / wgs_x;
+
+  const int nk = (int)(p.K / 64);
+  const int64_t lda2 = p.lda * 2, ldb2 = p.ldb * 2;
+  // per-thread byte offsets of a part's chunks (see gemm8.hip): row r0 (+ 64 j), chunk column swizzled by the row
+  unsigned voff_a, voff_b;
+  {
+    const int r0 = tid >> 3, cpos = tid & 7;
+    const int c = cpos ^ (r0 & 7);
+    const int rb = (r0 >> 5) * 64 + (r0 & 31);        // B parts interleave the four wave columns' 32-row halves
+    voff_a = (unsigned)((r0 * p.lda + c * 8) * 2);
+    voff_b = (unsigned)((rb * p.ldb + c * 8) * 2);
+  }
+  const unsigned ring = pp_lds(smem);
+  const unsigned dst_lane = (unsigned)(wave_u * 64) * 16;   // this wave's 1 KB piece inside each 8 KB half-part
+
+  // issue one part (two DMA instructions per thread): kind 0 B0, 1 B1, 2 A1, 3 A0 of K-tile `kt` into ring half `half`
+  auto issue = [&](auto kind_tag, const PpBases& bs, int kt, int half) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    const unsigned slot = ring + (unsigned)(half * 4 + KIND) * PP_PART + dst_lane;
+    const unsigned koff = (unsigned)kt * 128u;
+    if constexpr (KIND == 0 || KIND == 1) {
+      pp_dma(bs.b[KIND][0], voff_b + koff, slot);
+      pp_dma(bs.b[KIND][1], voff_b + koff, slot + 512 * 16);
+    } else {
+      constexpr int MQ = KIND == 2 ? 1 : 0;
+      pp_dma(bs.a[MQ][0], voff_a + koff, slot);
+      pp_dma(bs.a[MQ][1], voff_a + koff, slot + 512 * 16);
+    }
+  };
+  // the same for the NEXT tile (tail of the K loop, once per tile): only its two origin pointers are kept in SGPRs, the
+  // row-group bases are derived at the issue site (a handful of SALU instructions per part)
+  auto issue_next = [&](auto kind_tag, const char* a0n, const char* b0n, int kt, int half) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    const unsigned slot = ring + (unsigned)(half * 4 + KIND) * PP_PART + dst_lane;
+    const unsigned koff = (unsigned)kt * 128u;
+    if constexpr (KIND == 0 || KIND == 1) {
+      pp_dma(b0n + (int64_t)(KIND * 32) * ldb2, voff_b + koff, slot);
+      pp_dma(b0n + (int64_t)(128 + KIND * 32) * ldb2, voff_b + koff, slot + 512 * 16);
+    } else {
+      constexpr int MQ = KIND == 2 ? 1 : 0;
+      pp_dma(a0n + (int64_t)(MQ * 64) * lda2, voff_a + koff, slot);
+      pp_dma(a0n + (int64_t)(128 + MQ * 64) * lda2, voff_a + koff, slot + 512 * 16);
+    }
+  };
+  using K_B0 = std::integral_constant<int, 0>;
+  using K_B1 = std::integral_constant<int, 1>;
+  using K_A1 = std::integral_constant<int, 2>;
+  using K_A0 = std::integral_constant<int, 3>;
+
+  // per-lane fragment byte offsets inside a part (rows are 128 B, chunks XOR-swizzled by row & 7)
+  int a_off[4][2], b_off[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    const int c = ks * 4 + fg;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int pr = wm * 64 + i * 16 + frow;
+      a_off[i][ks] = pr * 128 + ((c ^ (pr & 7)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int pr = wn * 32 + j * 16 + frow;
+      b_off[j][ks] = pr * 128 + ((c ^ (pr & 7)) * 16);
+    }
+  }
+
+  f32x4_t acc[8][4];
+  bf16x8_t ra0[4][2], ra1[4][2], rb0[2][2], rb1[2][2];  // [fragment][k-step]
+
+  auto read_a = [&](bf16x8_t (&ra)[4][2], const char* slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) ra[i][ks] = *(const bf16x8_t*)(slot + a_off[i][ks]);
+  };
+  auto read_b = [&](bf16x8_t (&rb)[2][2], const char* slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) rb[j][ks] = *(const bf16x8_t*)(slot + b_off[j][ks]);
+  };
+  // 16 MFMAs of one accumulator quadrant with NR ds_read_b128 of the NEXT register set spread underneath them
+  auto mma_rd = [&](auto quad_tag, const bf16x8_t (&rb)[2][2], const bf16x8_t (&ra)[4][2], auto nr_tag, auto&& rd)
+                    __attribute__((always_inline)) {
+    constexpr int QI = decltype(quad_tag)::value >> 1, QJ = decltype(quad_tag)::value & 1;   // accumulator quadrant
+    constexpr int NR = decltype(nr_tag)::value;   // 0, 4 (a B set) or 8 (an A set)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[4 * QI + i][2 * QJ + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[j][ks], ra[i][ks], acc[4 * QI + i][2 * QJ + j], 0, 0, 0);
+          const int m = ks * 8 + i * 2 + j;
+          if constexpr (NR == 8) {
+            if (m % 2 == 0) rd(m / 2);
+          } else if constexpr (NR == 4) {
+            if (m % 4 == 0) rd(m / 4);
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+    // pin the interleave (otherwise the scheduler hoists every read in front of the first MFMA)
+    if constexpr (NR == 8) {
+#pragma unroll
+      for (int f = 0; f < 8; f++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    } else if constexpr (NR == 4) {
+#pragma unroll
+      for (int f = 0; f < 4; f++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  };
+  using NR0 = std::integral_constant<int, 0>;
+  using NR4 = std::integral_constant<int, 4>;
+  using NR8 = std::integral_constant<int, 8>;
+  using Q00 = std::integral_constant<int, 0>;
+  using Q01 = std::integral_constant<int, 1>;
+  using Q10 = std::integral_constant<int, 2>;
+  using Q11 = std::integral_constant<int, 3>;
+
+  PpBases cur;                              // wave-uniform (SGPR) row-group base pointers of the current tile
+  const char *a0n = nullptr, *b0n = nullptr;   // origin pointers of the next tile
+
+  // One K-tile = four {load section, barrier, compute section, barrier}; `t` = K-tile index inside the tile, `h` = its ring
+  // half.  MODE selects what the load sections issue and wait for (table in the header comment).
+  auto k_tile = [&](auto mode_tag, int t, int h) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool HEAD0 = MODE == PP_HEAD0, HEAD1 = MODE == PP_HEAD1, TAIL0 = MODE == PP_TAIL0, TAIL1 = MODE == PP_TAIL1;
+    const char* half_c = smem + h * 4 * PP_PART;
+    const int ho = h ^ 1;
+    // ---------------- phase 0: rb0 <- B0(t); issue B1(t+1); compute (rb0, ra0) with the reads of rb1 <- B1(t) underneath
+    read_b(rb0, half_c + 0 * PP_PART);
+    if constexpr (TAIL1) {
+      issue_next(K_B1{}, a0n, b0n, 0, ho);
+      pp_wait<6>();
+    } else if constexpr (!HEAD0) {
+      issue(K_B1{}, cur, t + 1, ho);
+      if constexpr (!HEAD1) pp_wait<6>();
+    }
+    pp_bar();
+    mma_rd(Q00{}, rb0, ra0, NR4{}, [&](int f) { rb1[f >> 1][f & 1] = *(const bf16x8_t*)(half_c + 1 * PP_PART + b_off[f >> 1][f & 1]); });
+    pp_bar();
+    // ---------------- phase 1: issue A1(t+1); compute (rb1, ra0) with ra1 <- A1(t) underneath
+    if constexpr (TAIL1) {
+      issue_next(K_A1{}, a0n, b0n, 0, ho);
+      pp_wait<6>();
+    } else if constexpr (!HEAD0) {
+      issue(K_A1{}, cur, t + 1, ho);
+      pp_wait<6>();
+    }
+    pp_bar();
+    mma_rd(Q01{}, rb1, ra0, NR8{}, [&](int f) { ra1[f >> 1][f & 1] = *(const bf16x8_t*)(half_c + 2 * PP_PART + a_off[f >> 1][f & 1]); });
+    pp_bar();
+    // ---------------- phase 2: issue A0(t+2); compute (rb1, ra1) with ra0 <- A0(t+1) underneath (not in the last K-tile)
+    if constexpr (TAIL1) {
+      issue_next(K_A0{}, a0n, b0n, 1, ho);
+    } else if constexpr (TAIL0) {
+      issue_next(K_A0{}, a0n, b0n, 0, ho);
+      pp_wait<6>();
+    } else {
+      issue(K_A0{}, cur, t + 2, ho);
+      if constexpr (!HEAD0) pp_wait<6>();
+    }
+    pp_bar();
+    if constexpr (TAIL1) {
+      mma_rd(Q11{}, rb1, ra1, NR0{}, [&](int) {});
+    } else {
+      mma_rd(Q11{}, rb1, ra1, NR8{}, [&](int f) { ra0[f >> 1][f & 1] = *(const bf16x8_t*)(half_c + 3 * PP_PART + a_off[f >> 1][f & 1]); });
+    }
+    pp_bar();
+    // ---------------- phase 3: issue B0(t+2) into the slot of B0(t); compute (rb0, ra1)
+    if constexpr (TAIL1) {
+      issue_next(K_B0{}, a0n, b0n, 1, h);
+      issue_next(K_B1{}, a0n, b0n, 1, h);    // slot (h, 1) was last read under the MFMAs of phase 0: two phases ago
+      issue_next(K_A1{}, a0n, b0n, 1, h);    // slot (h, 2) was last read under the MFMAs of phase 1: two phases ago
+    } else if constexpr (TAIL0) {
+      issue_next(K_B0{}, a0n, b0n, 0, h);
+      pp_wait<6>();
+    } else {
+      issue(K_B0{}, cur, t + 2, h);
+      if constexpr (!HEAD0) pp_wait<6>();
+    }
+    pp_bar();
+    mma_rd(Q10{}, rb0, ra1, NR0{}, [&](int) {});
+    pp_bar();
+  };
+  using M_STEADY = std::integral_constant<int, PP_STEADY>;
+  using M_HEAD0 = std::integral_constant<int, PP_HEAD0>;
+  using M_HEAD1 = std::integral_constant<int, PP_HEAD1>;
+  using M_TAIL0 = std::integral_constant<int, PP_TAIL0>;
+  using M_TAIL1 = std::integral_constant<int, PP_TAIL1>;
+
+  // ---- first tile: parts -1 .. 5 in flight, all landed before anybody reads
+  int64_t m0, n0;
+  pp_tile_origin(p, band0 + pos, m0, n0);
+  pp_make_bases(cur, (const char*)(p.A + m0 * p.lda), (const char*)(p.B + n0 * p.ldb), lda2, ldb2);
+  int h = 0;                                   // ring half of the current tile's K-tile 0 (toggles every K-tile, across tiles)
+  issue(K_A0{}, cur, 0, 1);                    // part -1: A0(0) -> half h^1, slot 3
+  issue(K_B0{}, cur, 0, 0);
+  issue(K_B1{}, cur, 0, 0);
+  issue(K_A1{}, cur, 0, 0);
+  issue(K_A0{}, cur, 1, 0);
+  issue(K_B0{}, cur, 1, 1);
+  issue(K_B1{}, cur, 1, 1);
+  issue(K_A1{}, cur, 1, 1);
+  pp_wait<0>();
+
+  for (int ti = 0; ti < my_tiles; ti++) {
+    const bool has_next = ti + 1 < my_tiles;   // workgroup-uniform
+    int64_t m0n, n0n;
+    pp_tile_origin(p, band0 + pos + (has_next ? ti + 1 : ti) * wgs_x, m0n, n0n);
+    a0n = (const char*)(p.A + m0n * p.lda);
+    b0n = (const char*)(p.B + n0n * p.ldb);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // ---- tile start: every part up to 6 of this tile landed before this wave's last vmcnt(0); the barrier makes all
+    //      waves' pieces visible; ra0 <- A0(0), then straight into K-tile 0 (whose first load section reads rb0)
+    pp_bar();
+    if (late_group) pp_bar();
+    read_a(ra0, smem + ((h ^ 1) * 4 + 3) * PP_PART);
+    k_tile(M_HEAD0{}, 0, h);
+    k_tile(M_HEAD1{}, 1, h ^ 1);
+    int t = 2;
+    for (; t < nk - 2; t++) k_tile(M_STEADY{}, t, h ^ (t & 1));
+    // ONE tail for every tile: the last tile "prefetches" its own first parts again (never read; retired by the
+    // epilogue's vmcnt(0)).  A has_next diamond around two copies of the tail costs ~300 spilled VGPRs (hipcc 7.2).
+    k_tile(M_TAIL0{}, nk - 2, h ^ (nk & 1));
+    k_tile(M_TAIL1{}, nk - 1, h ^ ((nk - 1) & 1));
+    if (!late_group) pp_bar();   // the early group matches the late group's extra barrier
+    h ^= (nk & 1);               // ring half of the next tile's K-tile 0
+
+    // ---- epilogue: staged through this wave's private 4 KB (the ring holds the next tile's parts).  Its first action
+    //      (bias loads + s_waitcnt vmcnt(0)) also retires every LDS-DMA this wave has issued.
+    if (p.dbg & 1) {   // diagnostics: no output traffic (keeps the accumulators alive through one predicated store)
+      pp_wait<0>();
+      if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 0.5f) *(float*)p.C = acc[3][2][1];
+    } else {
+      // lane id re-derived through a VOLATILE asm: everything the epilogue computes from it (LDS staging offsets, row /
+      // column addresses) is then re-computed per tile instead of being hoisted out of the tile loop, where it would
+      // sit in VGPRs across the K loop (the K loop owns all 256)
+      int elane;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
+      const int efrow = elane & 15, efg = elane >> 4;
+      pp_wait<0>();
+      (void)gemm_epilogue_try_staged<EPI, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+                                             smem + PP_RING + wave_u * PP_STAGE_PER_WAVE);
+    }
+    m0 = m0n;
+    n0 = n0n;
+    pp_make_bases(cur, a0n, b0n, lda2, ldb2);
+  }
+}
+
+int g_num_cus2 = 0;
+
+}  // namespace
+
+// true when the persistent kernel can run this problem (otherwise the caller keeps the one-tile-per-workgroup kernel)
+template <int EPI>
+static bool persist2_ok(const GemmArgs& a, int ncu) {
+  if (EPI == EPI_F32) return false;
+  if (a.M < 256 || a.N < 256 || a.K % 64 != 0 || a.K < 256) return false;
+  const int64_t tiles = cdiv64(a.M, 256) * cdiv64(a.N, 256);
+  if (tiles <= ncu) return false;                                   // one round: nothing to overlap
+  if (a.N % 8 != 0 || a.ldc % 8 != 0 || ((uintptr_t)a.C & 15) != 0) return false;
+  if (EPI == EPI_GELU && a.aux_out != nullptr && (a.ldaux % 8 != 0 || ((uintptr_t)a.aux_out & 15) != 0)) return false;
+  if (a.lda >= (1 << 23) || a.ldb >= (1 << 23)) return false;            // 32-bit per-lane byte offsets
+  // shifted edge tiles recompute (and rewrite, bit-identically) rows / columns of their neighbours: inputs must not alias C
+  auto overlaps = [&](const void* q, int64_t ld) {
+    if (q == nullptr) return false;
+    const char* c0 = (const char*)a.C;
+    const char* c1 = c0 + (a.M * a.ldc) * 2;
+    const char* q0 = (const char*)q;
+    const char* q1 = q0 + (a.M * ld) * 2;
+    return q0 < c1 && c0 < q1;
+  };
+  if (overlaps(a.res, a.ldr) || overlaps(a.aux_in, a.ldaux) || overlaps(a.A, a.lda)) return false;
+  return true;
+}
+
+template <int EPI>
+static int launch8p2(const GemmArgs& a, hipStream_t stream) {
+  constexpr int smem = PP_RING + 8 * PP_STAGE_PER_WAVE;   // 160 KB: the whole LDS of a CU
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_8phase_persist2_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    return true;
+  }();
+  (void)attr_set;
+  GemmArgs b = a;
+  b.tiles_m = (int)cdiv64(a.M, 256);
+  b.tiles_n = (int)cdiv64(a.N, 256);
+  b.splitk = 1;
+  b.ws = nullptr;
+  b.ktiles_per = (int)(a.K / 64);
+  const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
+  // Grid: the tile count is fixed, so the kernel takes `rounds` = ceil(tiles / CUs) tile times whatever the grid is; the
+  // SMALLEST grid that still needs only `rounds` tiles per workgroup leaves the other CUs to the step's second stream for
+  // the whole launch instead of idling them in a ragged last round (588 tiles: 200 workgroups x 3 tiles, 56 CUs free,
+  // rather than 256 workgroups of which 180 run a third tile).  Equal workgroup counts per XCD keep the bands balanced.
+  // Option gemm_persist = 2 launches one workgroup per CU regardless (A/B).
+  int grid = g_num_cus2;
+  if (vj_opt(VJ_OPT_GEMM_PERSIST) != 2) {
+    const int64_t rounds = cdiv64(tiles, g_num_cus2);
+    const int64_t band = cdiv64(tiles, 8);                  // tiles of the largest XCD band
+    int64_t per_xcd = cdiv64(band, rounds);
+    if (per_xcd * 8 > g_num_cus2) per_xcd = g_num_cus2 / 8;
+    grid = (int)(per_xcd * 8);
+  }
+  hipLaunchKernelGGL(gemm_nt_8phase_persist2_kernel<EPI>, dim3(grid), dim3(512), smem, stream, b);
+  VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase)");
+  return 0;
+}
+
+// entry used by gemm.hip's dispatcher: returns VJ_PERSIST_NA when the persistent kernel does not apply (the caller falls
+// back to the one-tile-per-workgroup kernel), 0 after a launch, a hipError_t when the launch failed
+int vj_gemm_launch_8phase_persist2(const GemmArgs& a, int epilogue, hipStream_t stream) {
+  if (g_num_cus2 == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      return -100;
+    g_num_cus2 = n;
+  }
+  switch (epilogue) {
+    case EPI_BF16: return persist2_ok<EPI_BF16>(a, g_num_cus2) ? launch8p2<EPI_BF16>(a, stream) : -100;
+    case EPI_GELU: return persist2_ok<EPI_GELU>(a, g_num_cus2) ? launch8p2<EPI_GELU>(a, stream) : -100;
+    case EPI_DGELU: return persist2_ok<EPI_DGELU>(a, g_num_cus2) ? launch8p2<EPI_DGELU>(a, stream) : -100;
+    default: return -100;
+  }
+}

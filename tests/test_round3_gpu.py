@@ -102,15 +102,16 @@ def test_persistent_gemm_is_bit_identical_to_the_one_tile_kernel(M, N, K):
             old = set_option("gemm_persist", 0)
             try:
                 ref, ref_aux = _run_gemm(*ops_in, epi, with_aux)
-                set_option("gemm_persist", 1)
-                got, got_aux = _run_gemm(*ops_in, epi, with_aux)
+                for mode in (1, 3):   # 1: gemm8p.hip, 3: gemm8p2.hip (fragment reads under the MFMAs)
+                    set_option("gemm_persist", mode)
+                    got, got_aux = _run_gemm(*ops_in, epi, with_aux)
+                    torch.cuda.synchronize()
+                    assert not torch.isnan(got.float()).any(), (mode, epi, with_res, with_aux, seed, "unwritten output")
+                    assert torch.equal(got, ref), (mode, epi, with_res, with_aux, seed, int((got != ref).sum()))
+                    if with_aux:
+                        assert torch.equal(got_aux, ref_aux), (mode, epi, seed, "aux")
             finally:
                 set_option("gemm_persist", old)
-            torch.cuda.synchronize()
-            assert not torch.isnan(got.float()).any(), (epi, with_res, with_aux, seed, "unwritten output")
-            assert torch.equal(got, ref), (epi, with_res, with_aux, seed, int((got != ref).sum()))
-            if with_aux:
-                assert torch.equal(got_aux, ref_aux), (epi, seed, "aux")
         A, W, bias, res, aux_in = ops_in
         y = A.float() @ W.float().t()
         if epi != 2:
