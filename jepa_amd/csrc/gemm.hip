@@ -265,7 +265,6 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
 int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);  // gemm8.hip
 int vj_gemm_launch_4w(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);      // gemm4w.hip
 int vj_gemm_launch_8phase_persist(const GemmArgs& a, int epilogue, hipStream_t stream);                        // gemm8p.hip (-100: n/a)
-int vj_gemm_launch_8phase_persist2(const GemmArgs& a, int epilogue, hipStream_t stream);                       // gemm8p2.hip (-100: n/a)
 
 template <int EPI>
 static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
@@ -301,9 +300,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     // persistent variant (gemm8p.hip): one workgroup per CU walks its tiles, next tile's operands prefetched under the
     // current tile, epilogue stores drained under the next K loop; bit-identical outputs.  Run-time option "gemm_persist".
     if (EPI != EPI_F32 && vj_opt(VJ_OPT_GEMM_PERSIST) != 0 && a.dbg < 2) {
-      // gemm_persist = 3: second schedule (gemm8p2.hip: fragment reads under the MFMAs, prefetch distance 5)
-      const int rc = vj_opt(VJ_OPT_GEMM_PERSIST) == 3 ? vj_gemm_launch_8phase_persist2(a, EPI, stream)
-                                                        : vj_gemm_launch_8phase_persist(a, EPI, stream);
+      const int rc = vj_gemm_launch_8phase_persist(a, EPI, stream);
       if (rc != -100) return rc;
     }
     return vj_gemm_launch_8phase(a, EPI, ws, ws_bytes, stream);

@@ -11,7 +11,7 @@ enum VjOpt {
   VJ_OPT_GEMM_DGRAD_FLAGS,     // ... for the chains' dgrad GEMMs
   VJ_OPT_GEMM_4W,              // 1: every forward / dgrad GEMM on the 4-wave 256x128 kernel; 2: per-shape policy
   VJ_OPT_GEMM_PERSIST,         // 1 (default): persistent 8-phase kernel (gemm8p.hip) where it applies, trimmed grid; 2: one
-                               // workgroup per CU; 3: second schedule (gemm8p2.hip); 0: always one tile per workgroup (gemm8.hip)
+                               // workgroup per CU; 0: always one tile per workgroup (gemm8.hip)
   VJ_OPT_WGRAD_LANES,          // weight-gradient lanes of vj_blocks_bwd (1 or 2)
   VJ_OPT_WGRAD_TN,             // 1 (default): transpose-free weight gradients (gemm8_tn.hip); 0: transposes + NT GEMM
   VJ_OPT_ATTN_BWD_FUSED,       // 1: single-pass attention backward (attention_bwd1.hip) where it applies

@@ -102,7 +102,7 @@ def test_persistent_gemm_is_bit_identical_to_the_one_tile_kernel(M, N, K):
             old = set_option("gemm_persist", 0)
             try:
                 ref, ref_aux = _run_gemm(*ops_in, epi, with_aux)
-                for mode in (1, 3):   # 1: gemm8p.hip, 3: gemm8p2.hip (fragment reads under the MFMAs)
+                for mode in (1, 2):   # 1: trimmed grid (default), 2: one workgroup per CU
                     set_option("gemm_persist", mode)
                     got, got_aux = _run_gemm(*ops_in, epi, with_aux)
                     torch.cuda.synchronize()

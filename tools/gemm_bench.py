@@ -45,8 +45,8 @@ def main():
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
         res = []
         for c, q in cfgs:
-            flags = 0x100 if c == 4 else (0 if c in (8, 9) else (c << 4) | (q << 6))
-            set_option("gemm_persist", 1 if c == 8 else (3 if c == 9 else 0))   # 8.0: gemm8p.hip, 9.0: gemm8p2.hip
+            flags = 0x100 if c == 4 else (0 if c == 8 else (c << 4) | (q << 6))
+            set_option("gemm_persist", 1 if c == 8 else 0)
 
             def run():
                 if epi == 3:
