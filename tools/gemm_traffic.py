@@ -62,12 +62,14 @@ def run():
         bias = torch.randn(N, device=dev, generator=g)
         other = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16) if extra else None
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
+        if epi == 3:   # weight gradient, transpose-free route (the default): dY [T, N_out], X [T, K_in] token-major
+            dY, X = A.t().contiguous(), B.t().contiguous()
         flush = torch.randn(96 << 20, device=dev, generator=g)   # 384 MB: pushes the operands out of the Infinity Cache
         del flush
         torch.cuda.synchronize()
         check(lib.vj_probe_copy(mark_src.data_ptr(), mark_dst.data_ptr(), 4096, st), "marker")
         if epi == 3:
-            ops.gemm_wgrad(A, B, out)
+            ops.gemm_wgrad_tn(dY, X, out)
         elif epi == 1:
             ops.gemm_nt(A, B, out=out, bias=bias, aux_out=other, epilogue=1)
         elif epi == 2:
@@ -91,7 +93,7 @@ def per_shape(d, counter):
             out.append(cur)
         elif cur is not None and ("gemm" in name or "splitk_reduce" in name):
             cur["kb"] += float(r["Counter_Value"])
-            cur["kernels"].append(name.split("(")[0].replace("void ", "")[:44])
+            cur["kernels"].append(name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:44])
             cur["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     return out
 
@@ -99,7 +101,7 @@ def per_shape(d, counter):
 def summary(fd, wd, out_md):
     fe, wr = per_shape(fd, "FETCH_SIZE"), per_shape(wd, "WRITE_SIZE")
     assert len(fe) == len(wr) == len(SHAPES), (len(fe), len(wr), len(SHAPES))
-    lines = ["# Round 2: per-shape HBM traffic of the step's GEMMs, PMC vs algorithmic", "",
+    lines = ["# Per-shape HBM traffic of the step's GEMMs, PMC vs algorithmic (default kernel selection: persistent 8-phase, TN weight gradients)", "",
              "`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) over `python tools/gemm_traffic.py run`: one "
              "launch per shape, operands evicted from the Infinity Cache first.  Bytes = FETCH_SIZE x 2 (gfx950 counts 128-byte "
              "requests at 64 bytes) + WRITE_SIZE, both reported in KB.  Algorithmic = every operand read once + every output "

@@ -15,7 +15,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     name = name.split("(")[0]
     return name[:90]
 

@@ -22,7 +22,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name).split("(")[0]
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").split("(")[0]
     return name[:70]
 
 
