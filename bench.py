@@ -352,17 +352,20 @@ def main():
         # HBM bytes per launch of the dominant kernel: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
         # correction + WRITE_SIZE), committed under profiles/ -- counters cannot be collected from inside this process
         traffic, traffic_src = None, None
-        for pmc_name in ("r02_hbm_pmc.json", "r01_hbm_pmc.json"):
+        for pmc_name in ("r03_hbm_pmc.json", "r02_hbm_pmc.json", "r01_hbm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and args.workload == "vitl16":
                 with open(pmc) as fjs:
-                    ent = json.load(fjs).get("gemm_nt_8phase_kernel<0>")
+                    tab = json.load(fjs)
+                ent = tab.get("gemm_nt_8phase_persist_kernel<0>") or tab.get("gemm_nt_8phase_kernel<0>")
                 if ent:
                     traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/" + pmc_name
                     break
         roof = {"bound": "mfma",
-                "kernel": "bf16 MFMA GEMM family (gemm_nt_8phase_kernel 256x256 staggered 8-phase + gemm_nt_kernel "
-                          "128x128 split-K wgrads; MFMA 16x16x32, LDS-DMA staged)",
+                "kernel": "bf16 MFMA GEMM family (gemm_nt_8phase_persist_kernel: persistent 256x256 staggered 8-phase, "
+                          "cross-tile LDS-DMA prefetch; gemm_nt_8phase_kernel for <= 256-tile problems; gemm_tn_8phase_kernel: "
+                          "transpose-free split-K weight gradients; MFMA 16x16x32); traffic = dominant kernel "
+                          "gemm_nt_8phase_persist_kernel<0>",
                 "achieved": round(ach / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
                 "traffic_source": traffic_src,

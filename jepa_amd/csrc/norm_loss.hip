@@ -33,12 +33,27 @@ __device__ __forceinline__ void store8(bf16_t* p, const float* v) {
 // ---------------------------------------------------------------------------------------------
 // layernorm_fwd: y = (x-mean)*rstd*gamma + beta  (bf16 in, bf16 out, fp32 math, biased variance)
 // ---------------------------------------------------------------------------------------------
+// gamma / beta are staged once per workgroup in LDS (fp32, in the order the lanes consume them: every lane's two
+// float4 halves of a chunk sit 1 KB apart, so a wave's ds_read_b128 covers 1 KB contiguously): re-reading them from
+// global memory for every row put 4x more bytes through the vector cache than the rows themselves (8 KB of affine
+// parameters against 2 KB of x per row at D = 1024).
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             int64_t rows, int D, float eps) {
+  __shared__ __attribute__((aligned(16))) float4 gbs[LN_MAX_CHUNKS][4][64];   // [chunk][gamma lo, gamma hi, beta lo, beta hi][lane]
   const int lane = threadIdx.x & 63;
+  for (int q = threadIdx.x; q < LN_MAX_CHUNKS * 64; q += 256) {
+    const int i = q >> 6, l = q & 63, c = l * 8 + i * 512;
+    if (c < D) {
+      gbs[i][0][l] = *(const float4*)(gamma + c);
+      gbs[i][1][l] = *(const float4*)(gamma + c + 4);
+      gbs[i][2][l] = *(const float4*)(beta + c);
+      gbs[i][3][l] = *(const float4*)(beta + c + 4);
+    }
+  }
+  __syncthreads();
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
   const float invD = 1.0f / (float)D;
@@ -74,9 +89,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     for (int i = 0; i < LN_MAX_CHUNKS; i++) {
       const int c = lane * 8 + i * 512;
       if (c < D) {
+        const float4 g0 = gbs[i][0][lane], g1 = gbs[i][1][lane], b0 = gbs[i][2][lane], b1 = gbs[i][3][lane];
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mean) * rstd * gamma[c + j] + beta[c + j];
+        for (int j = 0; j < 8; j++) o[j] = (v[i][j] - mean) * rstd * gm[j] + bt[j];
         store8(yp + c, o);
       }
     }
