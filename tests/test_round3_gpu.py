@@ -165,3 +165,58 @@ def test_layernorm_bwd_column_sums_of_dx(rows, D):
     # the first call of the with_cs arm ran with beta = 0: dgamma/dbeta equal the plain call's halves after the accumulate
     assert torch.allclose(outs[1][1], 2 * outs[0][1], rtol=1e-6, atol=1e-5)
     assert torch.allclose(outs[1][2], 2 * outs[0][2], rtol=1e-6, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel reducer at one rank
+def _reducer_worker(q):
+    """Own process: torch.distributed must be initialised (and destroyed) exactly once per process."""
+    try:
+        import socket
+        import torch.distributed as dist
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        res = {}
+        for mode in ("none", "torch", "capi"):
+            os.environ["VJ_FORCE_DP"] = "0" if mode == "none" else "1"
+            os.environ["VJ_COMM_BACKEND"] = "capi" if mode == "capi" else "torch"
+            tr, _, _, _, _ = build_trainer(TINY, 2, perturb_small=True)
+            assert tr.reducer.enabled == (mode != "none")
+            gens = _gens()
+            losses = []
+            for step in range(1, 3):
+                clips, me, mp = draw_batch(gens, 4, TINY, 300 + step, 400 + step)
+                out = tr.train_step(*to_dev(clips, me, mp), lr=1e-3, wd=0.04, ema=0.99)
+                losses.append(out.loss)
+            torch.cuda.synchronize()
+            if mode != "none":
+                assert len(tr.reducer.launched) == len(tr.reducer.buckets) + len(tr.reducer.tail)
+            res[mode] = (losses, tr.arena.G.clone().cpu(), tr.arena.P.clone().cpu(), tr.tarena.P.clone().cpu())
+        dist.destroy_process_group()
+        for mode in ("torch", "capi"):
+            assert res[mode][0] == res["none"][0], (mode, res[mode][0], res["none"][0])
+            for a, b in zip(res[mode][1:], res["none"][1:]):
+                assert torch.equal(a, b), mode
+        q.put("ok")
+    except BaseException as e:   # noqa: BLE001
+        import traceback
+        q.put(traceback.format_exc() + repr(e))
+
+
+@pytest.mark.timeout(300)
+def test_reducer_at_one_rank_leaves_the_step_bit_identical():
+    """with a 1-rank RCCL communicator the bucketed reducer (both backends: torch.distributed and the
+    C-ABI vj_comm_*) must leave losses, the gradient arena, the weights and the EMA target BIT-identical to the step without
+    a reducer -- a SUM over one rank is the identity, so any difference would be a ordering / stream bug in the bucket path."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_reducer_worker, args=(q,))
+    p.start()
+    msg = q.get(timeout=280)
+    p.join(30)
+    assert msg == "ok", msg
