@@ -98,6 +98,17 @@ int vj_gemm_bf16_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ld
 int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int64_t T,
                            int64_t N1, int64_t N2, float alpha, float beta, void* ws, int64_t ws_bytes,
                            vj_stream_t stream);
+/* The weight gradients of n <= 4 Linear layers over the SAME T tokens in ONE launch -- a transformer block's qkv, proj,
+ * fc1, fc2 (the four nn.Linear backward nodes of Block.forward, modules.py:31-34,63,76).  Per problem the contract of
+ * vj_gemm_bf16_tn_splitk; one split factor for the group; ws_bytes >= 4 * sum N1*N2 (more allows split-K). */
+typedef struct vj_tn_problem {
+  const void* dY; int64_t ldy; /* [T, N1] bf16 */
+  const void* X;  int64_t ldx; /* [T, N2] bf16 */
+  float* dW;      int64_t ldw; /* [N1, N2] fp32 */
+  int64_t N1, N2;
+} vj_tn_problem_t;
+int vj_gemm_bf16_tn_grouped(const vj_tn_problem_t* problems, int64_t n, int64_t T, float alpha, float beta, void* ws,
+                            int64_t ws_bytes, vj_stream_t stream);
 /* out[N, Mpad] = in[M,N]^T (zero padded): the wgrad operands dY^T, X^T; weight shadows W^T for dgrad. */
 int vj_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t Mpad,
                       vj_stream_t stream);
@@ -234,7 +245,8 @@ int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads);
  * (NULL = same stream), ordered by events; on return `side` may still hold pending work -- make the consumer of the
  * gradients wait on it.  on_layer_done(user, l) (nullable) is called from the enqueueing thread as soon as block l's
  * backward has been enqueued on both streams (gradient-bucket launch hook, DDP equivalent of train.py:295-297).
- * flags bit0: transpose-free weight gradients (vj_gemm_bf16_tn_splitk). */
+ * flags bit0: transpose-free weight gradients (vj_gemm_bf16_tn_splitk; with option "wgrad_group" the four of a block
+ * in one vj_gemm_bf16_tn_grouped launch once the block's last dY exists). */
 int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, const void* dout, void* dx_out, int64_t M,
                   int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float alpha, float beta_acc,
                   const void* save_ws, int64_t save_ws_bytes, void* tmp_ws, int64_t tmp_ws_bytes, int flags,
@@ -266,7 +278,7 @@ int vj_comm_destroy(vj_comm_t comm);
 /* ---- run-time tuning switches ------------------------------------------------------------------------------
  * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
  * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_lanes", "wgrad_tn",
- * "attn_bwd_fused", "reduce_inline", "gemm_dbg".  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * "wgrad_group", "gemm_dbg".  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
  * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
 int vj_set_option(const char* name, int value);
 int vj_get_option(const char* name, int* value);

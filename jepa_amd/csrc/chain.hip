@@ -257,6 +257,7 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
 
 // ---------------------------------------------------------------------------------------------------- backward
 #define WGRAD_WS_BYTES ((int64_t)96 << 20)
+#define GROUP_WS_BYTES ((int64_t)192 << 20)   // grouped weight gradients: 4 * sum N1*N2 (ViT-H: 79 MB) x split factor
 
 struct BwdLayout {
   int64_t du[2], dx1[2], dqkv[2], dx[3], dy2, dob, dy1, delta, ln_ws, dyT[2], xT[2], tcs_ws[2], wg_ws[2], total;
@@ -290,7 +291,7 @@ static BwdLayout bwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
     L.dyT[w] = take(nmax * Mp * 2);
     L.xT[w] = take(Dh * Mp * 2);
     L.tcs_ws[w] = take(L.tcs_ws_bytes);
-    L.wg_ws[w] = take(WGRAD_WS_BYTES);
+    L.wg_ws[w] = take(w == 0 ? GROUP_WS_BYTES : WGRAD_WS_BYTES);   // lane 0 also serves the grouped launch
   }
   L.total = off;
   return L;
@@ -348,6 +349,35 @@ static int wgrad(const SideCtx& c, const void* dy, const void* x_in, const vj_li
                                 WGRAD_WS_BYTES, st);
 }
 
+// The block's four weight gradients as ONE grouped launch (option wgrad_group): the bias column sums that no LayerNorm
+// backward produced go first, then vj_gemm_bf16_tn_grouped; everything on the side stream, after `main` produced the
+// last dY of the block.
+struct WgradItem {
+  const void* dy;
+  const void* x;
+  const vj_linear_t* lw;
+  bool bias_done;
+};
+static int wgrad_group(const SideCtx& c, const WgradItem* it, int n) {
+  hipStream_t st = c.side;
+  if (st != c.main) CH(stream_after(st, c.main, "vj_blocks_bwd(fork)"));
+  vj_tn_problem_t pr[4];
+  double fl = 0;
+  int64_t out_elems = 0;
+  for (int i = 0; i < n; i++) {
+    const vj_linear_t& lw = *it[i].lw;
+    const int64_t N = lw.n_out, K = lw.k_in, M = c.M;
+    if (lw.gb && !it[i].bias_done)
+      CH(vj_colsum_bf16(it[i].dy, M, N, N, M > 0 ? M : 1, 0, M > 0 ? M : 1, lw.gb, c.alpha, c.beta, c.tmp + c.L->tcs_ws[0],
+                        c.L->tcs_ws_bytes, st));
+    pr[i] = vj_tn_problem_t{it[i].dy, N, it[i].x, K, lw.gw, K, N, K};
+    fl += 2.0 * M * N * K;
+    out_elems += N * K;
+  }
+  ProfScope ps(st, 0, fl, out_elems / pr[0].N2, pr[0].N2, c.M, 4);
+  return vj_gemm_bf16_tn_grouped(pr, n, c.M, c.alpha, c.beta, c.tmp + c.L->wg_ws[0], GROUP_WS_BYTES, st);
+}
+
 extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, const void* dout, void* dx_out,
                              int64_t M, int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float alpha,
                              float beta_acc, const void* save_ws, int64_t save_ws_bytes, void* tmp_ws,
@@ -393,17 +423,22 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     // fc2: dgrad fused with GELU' ; wgrad reads (dx2, g)
     // dx2 of every block but the last is the dx of block li+1's norm1 backward, which also produced its column sums
     const bool fuse_cs = sc.tn != 0;   // (the NT route folds the bias gradient into its dY transpose instead)
-    CH(wgrad(sc, dx2, w + F.g, b.fc2, 0, fuse_cs && li + 1 < n_blocks));
+    const bool grouped = sc.tn != 0 && vj_opt(VJ_OPT_WGRAD_GROUP) != 0 && D % 8 == 0 && Dh % 8 == 0;
+    const WgradItem items[4] = {{dx2, w + F.g, &b.fc2, fuse_cs && li + 1 < n_blocks},
+                                {du, w + F.y2, &b.fc1, false},
+                                {dx1, w + F.o, &b.proj, fuse_cs},
+                                {dqkv, w + F.y1, &b.qkv, false}};
+    if (!grouped) CH(wgrad(sc, dx2, w + F.g, b.fc2, 0, fuse_cs && li + 1 < n_blocks));
     CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream, g_dgrad_flags));
     // fc1
-    CH(wgrad(sc, du, w + F.y2, b.fc1, 1));
+    if (!grouped) CH(wgrad(sc, du, w + F.y2, b.fc1, 1));
     CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     // dx1 is the dY of proj: its bias gradient = column sums of dx1, produced by this pass
     CH(vj_layernorm_bwd_colsum(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
                                dx1, b.norm2.gg, b.norm2.gb, fuse_cs ? b.proj.gb : nullptr, alpha, beta_acc, M, D,
                                tmp + L.ln_ws, L.ln_ws_bytes, stream));
     // proj
-    CH(wgrad(sc, dx1, w + F.o, b.proj, 0, fuse_cs));
+    if (!grouped) CH(wgrad(sc, dx1, w + F.o, b.proj, 0, fuse_cs));
     CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     for (int64_t s = 0; s < n_segs; s++) {
       const vj_seg_t& sg = segs[s];
@@ -414,7 +449,8 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
                      tmp + L.delta, L.delta_bytes, stream));
     }
     // qkv
-    CH(wgrad(sc, dqkv, w + F.y1, b.qkv, 1));
+    if (grouped) CH(wgrad_group(sc, items, 4));
+    else CH(wgrad(sc, dqkv, w + F.y1, b.qkv, 1));
     CH(gemm(dqkv, 3 * D, b.qkv.wT, b.qkv.ldwT, tmp + L.dy1, D, M, D, 3 * D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0,
             stream, g_dgrad_flags));
     // dx is the dY of the previous block's fc2 (its dx2): that bias gradient comes out of this pass

@@ -98,15 +98,41 @@ __device__ __forceinline__ void tn_issue_part(const GemmArgs& p, int q, int64_t 
   }
 }
 
-__global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(GemmArgs p) {
+// One launch for up to TN_GROUP_MAX problems that share the token count (the four weight gradients of a transformer
+// block): work units = (problem, K slice, tile), numbered problem-major; unit_end[i] = cumulative count.
+#define TN_GROUP_MAX 4
+struct TnGroupArgs {
+  int n;
+  int unit_end[TN_GROUP_MAX];
+  GemmArgs g[TN_GROUP_MAX];
+};
+struct TnSingleArgs {
+  GemmArgs g;
+};
+
+template <bool GROUPED>
+__global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<GROUPED, TnGroupArgs, TnSingleArgs> ga) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_u >> 2, wn = wave_u & 3;
   const bool late_group = wave_u >= 4;
 
+  GemmArgs p;
+  int logical_all;
+  if constexpr (GROUPED) {
+    const int l = xcd_logical(blockIdx.x, ga.unit_end[ga.n - 1]);
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < TN_GROUP_MAX; i++)
+      if (i + 1 < ga.n && l >= ga.unit_end[i]) idx = i + 1;
+    logical_all = l - (idx > 0 ? ga.unit_end[idx - 1] : 0);
+    p = ga.g[idx];
+  } else {
+    p = ga.g;
+    logical_all = xcd_logical(blockIdx.x, p.tiles_m * p.tiles_n * p.splitk);
+  }
   const int ntile = p.tiles_m * p.tiles_n;
-  const int logical_all = xcd_logical(blockIdx.x, ntile * p.splitk);
   const int slice = logical_all / ntile;
   int tm, tn;
   tile_of(logical_all - slice * ntile, p.tiles_m, p.tiles_n, tm, tn);
@@ -276,21 +302,7 @@ bf16_t* g_zero_row = nullptr;   // 128 bf16 zeros (one process drives one GPU)
 __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, int64_t N, int64_t ldc, int S,
                                      float alpha, float beta);   // gemm.hip
 
-// dW[N1,N2] = alpha * dY[T,N1]^T X[T,N2] + beta * dW.  (SURVEY 8a: backward of every nn.Linear on the path)
-extern "C" int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw,
-                                      int64_t T, int64_t N1, int64_t N2, float alpha, float beta, void* ws,
-                                      int64_t ws_bytes, hipStream_t stream) {
-  VJ_CHECK_ARG(T >= 0 && N1 >= 0 && N2 >= 0, "vj_gemm_bf16_tn_splitk: negative dim");
-  if (N1 == 0 || N2 == 0) return 0;
-  VJ_CHECK_ARG(T > 0, "vj_gemm_bf16_tn_splitk: T must be positive");
-  VJ_CHECK_ARG(N1 % 8 == 0 && N2 % 8 == 0, "vj_gemm_bf16_tn_splitk: N1=%ld, N2=%ld must be multiples of 8", (long)N1,
-               (long)N2);
-  VJ_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N1 && ldx >= N2 && ldy < (1 << 24) && ldx < (1 << 24),
-               "vj_gemm_bf16_tn_splitk: ldy/ldx must be multiples of 8, >= N1/N2 and < 2^24");
-  VJ_CHECK_ARG(((uintptr_t)dY % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)dW % 16 == 0),
-               "vj_gemm_bf16_tn_splitk: operands must be 16-byte aligned");
-  VJ_CHECK_ARG(ldw % 4 == 0 && ldw >= N2, "vj_gemm_bf16_tn_splitk: ldw=%ld must be a multiple of 4 and >= N2", (long)ldw);
-  VJ_CHECK_ARG(ws != nullptr && ws_bytes >= N1 * N2 * 4, "vj_gemm_bf16_tn_splitk: workspace must hold at least N1*N2 fp32");
+static int tn_zero_row() {
   if (g_zero_row == nullptr) {
     hipError_t e = hipMalloc((void**)&g_zero_row, 256);
     if (e == hipSuccess) e = hipMemset(g_zero_row, 0, 256);
@@ -300,13 +312,23 @@ extern "C" int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X
       return (int)e;
     }
   }
-  constexpr int smem = 8 * TN_PART_BYTES;
-  // function-local static with an initialiser: set exactly once, thread-safe (the C ABI is re-entrant)
-  static const bool attr_set = [] {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_8phase_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    return true;
-  }();
-  (void)attr_set;
+  return 0;
+}
+
+static int tn_check(const char* who, const void* dY, int64_t ldy, const void* X, int64_t ldx, const float* dW, int64_t ldw,
+                    int64_t T, int64_t N1, int64_t N2) {
+  VJ_CHECK_ARG(T > 0, "%s: T must be positive", who);
+  VJ_CHECK_ARG(N1 % 8 == 0 && N2 % 8 == 0, "%s: N1=%ld, N2=%ld must be multiples of 8", who, (long)N1, (long)N2);
+  VJ_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N1 && ldx >= N2 && ldy < (1 << 24) && ldx < (1 << 24),
+               "%s: ldy/ldx must be multiples of 8, >= N1/N2 and < 2^24", who);
+  VJ_CHECK_ARG(((uintptr_t)dY % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)dW % 16 == 0),
+               "%s: operands must be 16-byte aligned", who);
+  VJ_CHECK_ARG(ldw % 4 == 0 && ldw >= N2, "%s: ldw=%ld must be a multiple of 4 and >= N2", who, (long)ldw);
+  return 0;
+}
+
+static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int64_t T,
+                        int64_t N1, int64_t N2, float alpha, float beta) {
   GemmArgs b;
   b.A = (const bf16_t*)dY; b.B = (const bf16_t*)X; b.C = dW; b.bias = nullptr; b.res = nullptr; b.aux_in = nullptr;
   b.aux_out = nullptr;
@@ -316,20 +338,116 @@ extern "C" int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X
   b.tiles_n = (int)cdiv64(N2, 256);
   b.dbg = 0;
   b.zero_row = g_zero_row;
+  b.splitk = 1;
+  b.ktiles_per = (int)cdiv64(T, 64);
+  b.ws = nullptr;
+  return b;
+}
+
+static void tn_reduce(const GemmArgs& b, float alpha, float beta, hipStream_t stream) {
+  const int64_t n4 = b.M * b.N / 4;
+  int64_t g = cdiv64(n4, 256);
+  if (g > 256 * 8) g = 256 * 8;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float4*)b.ws, (float*)b.C, b.M, b.N,
+                     b.ldc, b.splitk, alpha, beta);
+}
+
+template <bool GROUPED>
+static void tn_set_attr() {
+  static const bool attr_set = [] {   // function-local static with an initialiser: set exactly once, thread-safe
+    (void)hipFuncSetAttribute((const void*)gemm_tn_8phase_kernel<GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              8 * TN_PART_BYTES);
+    return true;
+  }();
+  (void)attr_set;
+}
+
+// dW[N1,N2] = alpha * dY[T,N1]^T X[T,N2] + beta * dW.  (SURVEY 8a: backward of every nn.Linear on the path)
+extern "C" int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw,
+                                      int64_t T, int64_t N1, int64_t N2, float alpha, float beta, void* ws,
+                                      int64_t ws_bytes, hipStream_t stream) {
+  VJ_CHECK_ARG(T >= 0 && N1 >= 0 && N2 >= 0, "vj_gemm_bf16_tn_splitk: negative dim");
+  if (N1 == 0 || N2 == 0) return 0;
+  if (int rc = tn_check("vj_gemm_bf16_tn_splitk", dY, ldy, X, ldx, dW, ldw, T, N1, N2)) return rc;
+  VJ_CHECK_ARG(ws != nullptr && ws_bytes >= N1 * N2 * 4, "vj_gemm_bf16_tn_splitk: workspace must hold at least N1*N2 fp32");
+  if (int rc = tn_zero_row()) return rc;
+  tn_set_attr<false>();
+  TnSingleArgs a;
+  GemmArgs& b = a.g;
+  b = tn_args(dY, ldy, X, ldx, dW, ldw, T, N1, N2, alpha, beta);
   const int nk = (int)cdiv64(T, 64);
   b.splitk = pick_splitk((int64_t)b.tiles_m * b.tiles_n, nk, 256, 1.45, 8, N1, N2, ws_bytes);
   b.ws = (float*)ws;
   b.ktiles_per = (nk + b.splitk - 1) / b.splitk;
   b.splitk = (nk + b.ktiles_per - 1) / b.ktiles_per;
-  hipLaunchKernelGGL(gemm_tn_8phase_kernel, dim3(b.tiles_m * b.tiles_n * b.splitk), dim3(512), smem, stream, b);
+  hipLaunchKernelGGL(gemm_tn_8phase_kernel<false>, dim3(b.tiles_m * b.tiles_n * b.splitk), dim3(512), 8 * TN_PART_BYTES, stream, a);
   VJ_LAUNCH_CHECK("vj_gemm_bf16_tn_splitk");
   if (b.splitk > 1) {
-    const int64_t n4 = N1 * N2 / 4;
-    int64_t g = cdiv64(n4, 256);
-    if (g > 256 * 8) g = 256 * 8;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, (const float4*)b.ws, dW, N1, N2, ldw,
-                       b.splitk, alpha, beta);
+    tn_reduce(b, alpha, beta, stream);
     VJ_LAUNCH_CHECK("vj_gemm_bf16_tn_splitk(reduce)");
+  }
+  return 0;
+}
+
+// The weight gradients of n <= 4 Linear layers over the SAME T tokens in one launch (a transformer block's qkv, proj,
+// fc1, fc2: reference = the four nn.Linear backward nodes of Block.forward, modules.py:31-34,63,76).  Four separate
+// launches each pay their own pipeline fill, fp32 slice partials, slice reduction and tail; together the block's 192
+// (ViT-L) output tiles fill the GPU WITHOUT split-K, and the predictor's 38 tiles share one split factor.  The K-slice
+// length is common to the group; problem i's partials live at ws + sum_{j<i} splitk * N1_j * N2_j * 4.
+struct vj_tn_problem_abi {
+  const void* dY; int64_t ldy;
+  const void* X; int64_t ldx;
+  float* dW; int64_t ldw;
+  int64_t N1, N2;
+};
+extern "C" int vj_gemm_bf16_tn_grouped(const void* probs_v, int64_t n, int64_t T, float alpha, float beta, void* ws,
+                                       int64_t ws_bytes, hipStream_t stream) {
+  const vj_tn_problem_abi* pr = (const vj_tn_problem_abi*)probs_v;
+  VJ_CHECK_ARG(n >= 0 && n <= TN_GROUP_MAX, "vj_gemm_bf16_tn_grouped: n=%ld (at most %d problems)", (long)n, TN_GROUP_MAX);
+  VJ_CHECK_ARG(T >= 0, "vj_gemm_bf16_tn_grouped: negative T");
+  TnGroupArgs a;
+  a.n = 0;
+  int64_t tiles = 0, out_elems = 0;
+  for (int64_t i = 0; i < n; i++) {
+    VJ_CHECK_ARG(pr[i].N1 >= 0 && pr[i].N2 >= 0, "vj_gemm_bf16_tn_grouped: negative dim");
+    if (pr[i].N1 == 0 || pr[i].N2 == 0) continue;
+    if (int rc = tn_check("vj_gemm_bf16_tn_grouped", pr[i].dY, pr[i].ldy, pr[i].X, pr[i].ldx, pr[i].dW, pr[i].ldw, T, pr[i].N1,
+                          pr[i].N2))
+      return rc;
+    a.g[a.n] = tn_args(pr[i].dY, pr[i].ldy, pr[i].X, pr[i].ldx, pr[i].dW, pr[i].ldw, T, pr[i].N1, pr[i].N2, alpha, beta);
+    tiles += (int64_t)a.g[a.n].tiles_m * a.g[a.n].tiles_n;
+    out_elems += pr[i].N1 * pr[i].N2;
+    a.n++;
+  }
+  if (a.n == 0) return 0;
+  if (int rc = tn_zero_row()) return rc;
+  for (int i = 0; i < a.n; i++) a.g[i].zero_row = g_zero_row;
+  VJ_CHECK_ARG(ws != nullptr && ws_bytes >= out_elems * 4, "vj_gemm_bf16_tn_grouped: workspace must hold at least sum N1*N2 fp32");
+  const int nk = (int)cdiv64(T, 64);
+  // one split factor for the group: pick_splitk's cost model on the summed tile count / output size
+  int splitk = pick_splitk(tiles, nk, 256, 1.45, 8, out_elems, 1, ws_bytes);
+  const int ktiles_per = (nk + splitk - 1) / splitk;
+  splitk = (nk + ktiles_per - 1) / ktiles_per;
+  int64_t units = 0, ws_off = 0;
+  for (int i = 0; i < a.n; i++) {
+    a.g[i].splitk = splitk;
+    a.g[i].ktiles_per = ktiles_per;
+    a.g[i].ws = (float*)((char*)ws + ws_off);
+    ws_off += (int64_t)splitk * a.g[i].M * a.g[i].N * 4;
+    units += (int64_t)a.g[i].tiles_m * a.g[i].tiles_n * splitk;
+    a.unit_end[i] = (int)units;
+  }
+  for (int i = a.n; i < TN_GROUP_MAX; i++) {
+    a.unit_end[i] = (int)units;
+    a.g[i] = a.g[a.n - 1];
+  }
+  VJ_CHECK_ARG(units < (1ll << 31), "vj_gemm_bf16_tn_grouped: grid too large");
+  tn_set_attr<true>();
+  hipLaunchKernelGGL(gemm_tn_8phase_kernel<true>, dim3((unsigned)units), dim3(512), 8 * TN_PART_BYTES, stream, a);
+  VJ_LAUNCH_CHECK("vj_gemm_bf16_tn_grouped");
+  if (splitk > 1) {
+    for (int i = 0; i < a.n; i++) tn_reduce(a.g[i], alpha, beta, stream);
+    VJ_LAUNCH_CHECK("vj_gemm_bf16_tn_grouped(reduce)");
   }
   return 0;
 }

@@ -14,8 +14,8 @@ enum VjOpt {
                                // workgroup per CU; 0: always one tile per workgroup (gemm8.hip)
   VJ_OPT_WGRAD_LANES,          // weight-gradient lanes of vj_blocks_bwd (1 or 2)
   VJ_OPT_WGRAD_TN,             // 1 (default): transpose-free weight gradients (gemm8_tn.hip); 0: transposes + NT GEMM
-  VJ_OPT_ATTN_BWD_FUSED,       // 1: single-pass attention backward (attention_bwd1.hip) where it applies
-  VJ_OPT_REDUCE_INLINE,        // 1: last-arriver reductions inside the producers (no reduce_partials / splitk_reduce launches)
+  VJ_OPT_WGRAD_GROUP,          // 1 (default): the four weight gradients of a block in ONE launch (vj_gemm_bf16_tn_grouped);
+                               // 0: one launch each (different fp32 summation order: results agree to rounding, not bitwise)
   VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)
   VJ_OPT_COUNT
 };

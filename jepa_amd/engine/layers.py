@@ -128,12 +128,37 @@ def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0, bias_done: bo
     ops.gemm_wgrad(dyT, xT, lw.gw, alpha=alpha, beta=beta)
 
 
-def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None, beta: float = 0.0,
-                     bias_done: bool = False):
-    """dW (fp32, into lw.gw) = alpha * dy^T x_in + beta * dW ; db likewise ; returns dx = dy W (bf16).
-    The weight-gradient half goes to the side stream; the caller joins before the gradients are consumed."""
-    side = side_stream(dy.device)
+def _group_ok(bw) -> bool:
+    """Option wgrad_group: the four weight gradients of a block as one vj_gemm_bf16_tn_grouped launch (as vj_blocks_bwd)."""
+    return (_get_option("wgrad_tn") == 1 and _get_option("wgrad_group") != 0 and
+            all(d % 8 == 0 for lw in (bw.qkv, bw.proj, bw.fc1, bw.fc2) for d in lw.gw.shape))
+
+
+def _wgrad_group(items, alpha: float, beta: float):
+    """items: [(dy, x_in, lw, bias_done)] in the order fc2, fc1, proj, qkv: bias column sums first, then one launch."""
+    def run():
+        for dy, x_in, lw, bias_done in items:
+            if lw.gb is not None and not bias_done:
+                ops.colsum(dy, lw.gb, alpha=alpha, accumulate=beta != 0.0)
+        ops.gemm_wgrad_tn_grouped([(dy, x_in, lw.gw) for dy, x_in, lw, _ in items], alpha=alpha, beta=beta)
+    side = side_stream(items[0][0].device)
     if side.enabled:
+        side.fork(*[t for dy, x_in, _, _ in items for t in (dy, x_in)])
+        with torch.cuda.stream(side.stream):
+            run()
+    else:
+        run()
+
+
+def _linear_backward(dy, x_in, lw: LinearW, alpha: float, need_dx=True, dgelu_aux=None, beta: float = 0.0,
+                     bias_done: bool = False, defer=None):
+    """dW (fp32, into lw.gw) = alpha * dy^T x_in + beta * dW ; db likewise ; returns dx = dy W (bf16).
+    The weight-gradient half goes to the side stream; the caller joins before the gradients are consumed.
+    defer (list): only record the weight-gradient problem; the caller launches the block's group (_wgrad_group)."""
+    side = side_stream(dy.device)
+    if defer is not None:
+        defer.append((dy, x_in, lw, bias_done))
+    elif side.enabled:
         side.fork(dy, x_in)
         with torch.cuda.stream(side.stream):
             _wgrad(dy, x_in, lw, alpha, beta, bias_done)
@@ -158,16 +183,22 @@ def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: f
     scale = hd ** -0.5
     acc = beta != 0.0
     fuse = _tn_ok(8, 8)
-    du = _linear_backward(dx2, g, bw.fc2, alpha, dgelu_aux=u, beta=beta, bias_done=fuse and fc2_bias_done)   # fc2 dgrad fused with GELU'
-    dy2 = _linear_backward(du, y2, bw.fc1, alpha, beta=beta)
+    defer = [] if _group_ok(bw) else None
+    du = _linear_backward(dx2, g, bw.fc2, alpha, dgelu_aux=u, beta=beta, bias_done=fuse and fc2_bias_done, defer=defer)   # fc2 dgrad fused with GELU'
+    dy2 = _linear_backward(du, y2, bw.fc1, alpha, beta=beta, defer=defer)
     dx1 = ops.layernorm_bwd(dy2, x1, bw.norm2.g, mean2, rstd2, bw.norm2.gg, bw.norm2.gb, dres=dx2, alpha=alpha,
                             accumulate=acc, dxsum=bw.proj.gb if fuse else None)
-    do = _linear_backward(dx1, o, bw.proj, alpha, beta=beta, bias_done=fuse)
+    do = _linear_backward(dx1, o, bw.proj, alpha, beta=beta, bias_done=fuse, defer=defer)
     dqkv = torch.empty_like(qkv)
     for sg, lse in zip(segs, lses):
         ops.attn_bwd(_rows(qkv, sg), _rows(o, sg), _rows(do, sg), lse, sg.B, sg.S, heads, hd, scale,
                      out=_rows(dqkv, sg))
-    dy1 = _linear_backward(dqkv, y1, bw.qkv, alpha, beta=beta)
+    if defer is not None:
+        defer.append((dqkv, y1, bw.qkv, False))
+        _wgrad_group(defer, alpha, beta)
+        dy1 = ops.gemm_nt(dqkv, bw.qkv.wT)
+    else:
+        dy1 = _linear_backward(dqkv, y1, bw.qkv, alpha, beta=beta)
     return ops.layernorm_bwd(dy1, x, bw.norm1.g, mean1, rstd1, bw.norm1.gg, bw.norm1.gb, dres=dx1, alpha=alpha,
                              accumulate=acc, dxsum=prev_fc2_gb if fuse else None)
 

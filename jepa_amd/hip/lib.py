@@ -58,6 +58,7 @@ SIGNATURES = {
     "vj_gemm_bf16_nt": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, P, P, I64, I32, F32, F32, I32, P]),
     "vj_gemm_bf16_nt_splitk": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, F32, F32, I32, P, I64, P]),
     "vj_gemm_bf16_tn_splitk": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, F32, F32, P, I64, P]),
+    "vj_gemm_bf16_tn_grouped": (I32, [P, I64, I64, F32, F32, P, I64, P]),
     "vj_transpose_bf16": (I32, [P, P, I64, I64, I64, I64, P]),
     "vj_transpose_multi": (I32, [P, P, I64, P]),
     "vj_transpose_colsum_ws_bytes": (I64, [I64, I64]),

@@ -201,6 +201,7 @@ def gemm_nt(A, B, out=None, bias=None, residual=None, aux_in=None, aux_out=None,
 
 
 WGRAD_WS_BYTES = 96 << 20
+GROUP_WS_BYTES = 192 << 20   # the grouped launch's workspace, same size as the C chain's (same split factor -> same bits)
 
 
 def gemm_wgrad(dyT, xT, out, alpha=1.0, beta=0.0, flags=None, stream=None):
@@ -216,6 +217,26 @@ def gemm_wgrad(dyT, xT, out, alpha=1.0, beta=0.0, flags=None, stream=None):
     if _ev is not None:
         _ev.record()
     return out
+
+
+def gemm_wgrad_tn_grouped(problems, alpha=1.0, beta=0.0, stream=None):
+    """problems: [(dy [T, N1] bf16, x [T, N2] bf16, out [N1, N2] fp32), ...] (at most 4, same T): every out = alpha *
+    dy^T @ x + beta * out in ONE launch (vj_gemm_bf16_tn_grouped)."""
+    lib = load_library()
+    T = problems[0][0].shape[0]
+    flat = []
+    for dy, x, out in problems:
+        _req(dy, BF16, "dy")
+        _req(x, BF16, "x")
+        assert dy.shape[0] == T and x.shape[0] == T and out.shape == (dy.shape[1], x.shape[1]) and out.dtype == F32
+        flat += [dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), dy.shape[1], x.shape[1]]
+    arr = (ctypes.c_int64 * len(flat))(*[int(v) for v in flat])
+    ws = Scratch.get(GROUP_WS_BYTES, problems[0][0].device, "wgrad_group", stream=stream)
+    _ev = _timed("gemm_nt", sum(2.0 * T * dy.shape[1] * x.shape[1] for dy, x, _ in problems))
+    check(lib.vj_gemm_bf16_tn_grouped(ctypes.addressof(arr), len(problems), T, alpha, beta, _ptr(ws), GROUP_WS_BYTES,
+                                      _stream(stream)), "vj_gemm_bf16_tn_grouped")
+    if _ev is not None:
+        _ev.record()
 
 
 def gemm_wgrad_tn(dy, x, out, alpha=1.0, beta=0.0, stream=None):

@@ -167,7 +167,59 @@ def test_layernorm_bwd_column_sums_of_dx(rows, D):
     assert torch.allclose(outs[1][2], 2 * outs[0][2], rtol=1e-6, atol=1e-5)
 
 
+
+# ------------------------------------------------------------------------------------------------ grouped weight gradients
+@pytest.mark.parametrize("T,D,Dh", [(1000, 256, 1024), (777, 384, 1536), (4160, 1024, 4096), (70000, 128, 264)])
+def test_grouped_weight_gradients_match_the_single_launches(T, D, Dh):
+    """vj_gemm_bf16_tn_grouped (qkv, proj, fc1, fc2 of a block in one launch) against four vj_gemm_bf16_tn_splitk launches
+    and an fp64 reference, with alpha / beta accumulation.  The two kernels differ only in the split factor (fp32
+    summation order): rel-L2 <= 2e-6 between them, <= 2e-3 to fp64 (bf16 inputs, K = T up to 70000)."""
+    from jepa_amd.hip import ops
+    g = torch.Generator(device=DEV).manual_seed(T)
+    shapes = [(D, Dh), (Dh, D), (D, D), (3 * D, D)]            # (N1 = dY columns, N2 = X columns): fc2, fc1, proj, qkv
+    probs, singles, olds = [], [], []
+    for n1, n2 in shapes:
+        dy = (torch.randn(T, n1, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+        x = torch.randn(T, n2, device=DEV, generator=g).to(torch.bfloat16)
+        old = torch.randn(n1, n2, device=DEV, generator=g)
+        olds.append(old)
+        probs.append((dy, x, old.clone()))
+        singles.append((dy, x, old.clone()))
+    ops.gemm_wgrad_tn_grouped(probs, alpha=0.5, beta=1.0)
+    for dy, x, out in singles:
+        ops.gemm_wgrad_tn(dy, x, out, alpha=0.5, beta=1.0)
+    torch.cuda.synchronize()
+    for (dy, x, og), (_, _, os_), old in zip(probs, singles, olds):
+        ref = 0.5 * (dy.double().t() @ x.double()) + old.double()
+        assert rel_l2(og, os_) < 2e-6, rel_l2(og, os_)
+        assert rel_l2(og, ref) < 2e-3, rel_l2(og, ref)
+    # and a plain (beta = 0) run against fp64 directly
+    outs = [torch.empty(n1, n2, device=DEV) for n1, n2 in shapes]
+    ops.gemm_wgrad_tn_grouped([(p[0], p[1], o) for p, o in zip(probs, outs)], alpha=1.0, beta=0.0)
+    for (dy, x, _), o in zip(probs, outs):
+        ref = dy.double().t() @ x.double()
+        assert rel_l2(o, ref.float()) < 2e-3, rel_l2(o, ref.float())
+    again = [torch.empty_like(o) for o in outs]
+    ops.gemm_wgrad_tn_grouped([(p[0], p[1], o) for p, o in zip(probs, again)], alpha=1.0, beta=0.0)
+    for a, o in zip(again, outs):
+        assert torch.equal(a, o)       # deterministic
+
+
+def test_grouped_weight_gradients_argument_errors():
+    from jepa_amd.hip import ops
+    from jepa_amd.hip.lib import HipKernelError
+    dy = torch.zeros(64, 16, device=DEV, dtype=torch.bfloat16)
+    x = torch.zeros(64, 12, device=DEV, dtype=torch.bfloat16)      # 12 % 8 != 0
+    with pytest.raises(HipKernelError):
+        ops.gemm_wgrad_tn_grouped([(dy, x, torch.zeros(16, 12, device=DEV))])
+    x8 = torch.zeros(64, 16, device=DEV, dtype=torch.bfloat16)
+    five = [(dy, x8, torch.zeros(16, 16, device=DEV)) for _ in range(5)]
+    with pytest.raises(HipKernelError):
+        ops.gemm_wgrad_tn_grouped(five)
+
 # ------------------------------------------------------------------------------------------------ data-parallel reducer at one rank
+
+
 def _reducer_worker(q):
     """Own process: torch.distributed must be initialised (and destroyed) exactly once per process."""
     try:

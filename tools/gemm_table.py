@@ -9,7 +9,7 @@ import csv
 import sys
 
 FAM = {0: "GEMM", 1: "attention fwd", 2: "attention bwd"}
-EPI = {0: "bf16 (+bias/+res)", 1: "bias+GELU", 2: "dGELU", 3: "wgrad fp32 split-K"}
+EPI = {0: "bf16 (+bias/+res)", 1: "bias+GELU", 2: "dGELU", 3: "wgrad fp32 split-K", 4: "4 wgrads of a block, one launch (rows = sum N1*N2 / N)"}
 
 
 def main():
