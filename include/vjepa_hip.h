@@ -278,7 +278,7 @@ int vj_comm_destroy(vj_comm_t comm);
 /* ---- run-time tuning switches ------------------------------------------------------------------------------
  * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
  * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_lanes", "wgrad_tn",
- * "wgrad_group", "gemm_dbg".  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * "wgrad_group", "wgrad_slow_issue", "gemm_dbg".  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
  * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
 int vj_set_option(const char* name, int value);
 int vj_get_option(const char* name, int* value);
@@ -286,6 +286,9 @@ int vj_get_option(const char* name, int* value);
 /* ---- hardware probes (tests / profiles only) ---------------------------------------------------------------- */
 int vj_probe_tr16(uint32_t* out256, int addr_scale, vj_stream_t stream);
 int vj_probe_copy(const void* src, void* dst, int64_t bytes, vj_stream_t stream);
+/* LDS read throughput of a CU, 8 waves x iters x 8 back-to-back reads: mode 0 ds_read_b128, 1 ds_read_b64_tr_b16 (the TN
+ * GEMM's fragment addressing), 2 ds_read_b64; out[wg*8 + wave] = clock64 cycles (100 MHz timer ticks on gfx9) */
+int vj_probe_lds_bw(long long* out, int mode, int iters, int n_wgs, vj_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@
 // Split-K over the token tiles and the fp32 epilogue are shared with the NT kernels (gemm_common.hpp).
 #include <type_traits>
 #include "gemm_common.hpp"
+#include "options.hpp"
 
 #define TN_PART_BYTES 16384
 
@@ -96,6 +97,37 @@ __device__ __forceinline__ void tn_issue_part(const GemmArgs& p, int q, int64_t 
     }
     tn_dma16(src, tn_lds_addr(slot + (j * 512 + wave_u * 64) * 16));
   }
+}
+
+// ---- strength-reduced issue path of the K loop -------------------------------------------------------------------
+// tn_issue_part recomputes tile, kind, clamps and a 64-bit base per call: ~35 scalar + ~15 vector instructions per part,
+// 138 SALU per K-tile per wave (SQ_INSTS_SALU / SQ_INSTS_MFMA = 2.15 against 0.46 in the NT kernel), all of it inside the
+// load sections whose length sets the pace of the two wave groups.  Inside the loop every kind (A0, B0, B1, A1) is issued
+// exactly once per K-tile, so each keeps a running scalar base (token row 0 of the tile it loads next, column cbase) that
+// advances by 64 rows per issue; the per-lane part is one v_min (column clamp), one v_lshl_add (row0 * ld + column) and one
+// v_add (row0 + 32).  The generic form stays for the prologue, for a half that lies entirely outside the matrix and for the
+// last, partial token tile (row clamp / zero row).
+struct TnFast {
+  const char* base[4];    // per kind, bytes
+  int lim[4];             // per kind: last admissible source column (elements, relative to cbase); < 0: generic path only
+  unsigned step[2];       // bytes per K-tile (64 rows): [0] = A (dY), [1] = B (X)
+  unsigned row32[2];      // bytes of 32 rows
+  int tail_tile;          // slice-relative index of the partial token tile, or -1
+};
+__device__ __forceinline__ void tn_dma_sv(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+template <int KIND>
+__device__ __forceinline__ void tn_issue_fast(TnFast& f, int q, char* smem, int sc8, unsigned rowoff_a, unsigned rowoff_b,
+                                              int wave_u) {
+  constexpr bool isA = (KIND == 0) || (KIND == 3);
+  const unsigned slot = tn_lds_addr(smem + ((q + 8) & 7) * TN_PART_BYTES) + (unsigned)(wave_u * 64) * 16;
+  const int rel = sc8 < f.lim[KIND] ? sc8 : f.lim[KIND];
+  const unsigned v0 = (isA ? rowoff_a : rowoff_b) + ((unsigned)rel << 1);
+  const unsigned v1 = v0 + f.row32[isA ? 0 : 1];
+  tn_dma_sv(f.base[KIND], v0, slot);
+  tn_dma_sv(f.base[KIND], v1, slot + 512 * 16);
+  f.base[KIND] += f.step[isA ? 0 : 1];
 }
 
 // One launch for up to TN_GROUP_MAX problems that share the token count (the four weight gradients of a transformer
@@ -230,6 +262,34 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
   using NF4 = std::integral_constant<int, 4>;
   using NF8 = std::integral_constant<int, 8>;
 
+  // running bases of the strength-reduced issue path: after the prologue (parts -1 .. 4) the next part of kind A0 / B0
+  // belongs to K-tile 2 of this slice, of kind B1 / A1 to K-tile 1
+  TnFast fs;
+  {
+    const unsigned sa = (unsigned)p.lda * 128u, sb = (unsigned)p.ldb * 128u;   // 64 rows in bytes
+    fs.step[0] = sa;
+    fs.step[1] = sb;
+    fs.row32[0] = sa >> 1;
+    fs.row32[1] = sb >> 1;
+#pragma unroll
+    for (int kind = 0; kind < 4; kind++) {
+      const bool isA = (kind == 0) || (kind == 3);
+      const int half = (kind == 0 || kind == 1) ? 0 : 1;
+      const int64_t cbase = (isA ? m0 : n0) + half * 128;
+      const int first = (kind == 0 || kind == 1) ? 2 : 1;
+      const int64_t tok0 = (int64_t)(kt0 + first) * 64;
+      fs.base[kind] = (const char*)((isA ? p.A + tok0 * p.lda : p.B + tok0 * p.ldb) + cbase);
+      fs.lim[kind] = (int)((isA ? p.M : p.N) - cbase - 8);
+    }
+    fs.tail_tile = (p.K & 63) ? nk_all - 1 - kt0 : -1;
+  }
+  const unsigned rowoff_a = (unsigned)tl.row0 * (unsigned)p.lda * 2u, rowoff_b = (unsigned)tl.row0 * (unsigned)p.ldb * 2u;
+  auto issue_loop = [&](auto kind_tag, int q, int tile) __attribute__((always_inline)) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    if (tile != fs.tail_tile && fs.lim[KIND] >= 0 && !(p.dbg & 8)) tn_issue_fast<KIND>(fs, q, smem, tl.sc8, rowoff_a, rowoff_b, wave_u);
+    else tn_issue_part(p, q, m0, n0, kt0, smem, tl, wave_u);
+  };
+
   // ---- prologue: parts -1 .. 4 in flight; parts -1, 0, 1 landed for everyone
   tn_issue_part(p, -1, m0, n0, kt0, smem, tl, wave_u);
 #pragma unroll
@@ -261,7 +321,11 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
           for (int ks = 0; ks < 2; ks++) rb0[j][ks] = tn_frag(slot + b_off[j] + ks * 32 * 256);
       }
       if (q + 5 <= last_part) {
-        tn_issue_part(p, q + 5, m0, n0, kt0, smem, tl, wave_u);
+        // part q+5 = kind (ph + 2) & 3 of K-tile t+1 (ph 0, 1) / t+2 (ph 2, 3)
+        if (ph == 0) issue_loop(std::integral_constant<int, 2>{}, q + 5, t + 1);
+        else if (ph == 1) issue_loop(std::integral_constant<int, 3>{}, q + 5, t + 1);
+        else if (ph == 2) issue_loop(std::integral_constant<int, 0>{}, q + 5, t + 2);
+        else issue_loop(std::integral_constant<int, 1>{}, q + 5, t + 2);
         tn_wait_vm<6>();                              // part q+2 landed; q+3..q+5 in flight
       } else {
         wait_landed(q);
@@ -336,7 +400,7 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
   b.alpha = alpha; b.beta = beta;
   b.tiles_m = (int)cdiv64(N1, 256);
   b.tiles_n = (int)cdiv64(N2, 256);
-  b.dbg = 0;
+  b.dbg = vj_opt(VJ_OPT_WGRAD_SLOW_ISSUE) ? 8 : 0;   // A/B switch of the K loop's issue path
   b.zero_row = g_zero_row;
   b.splitk = 1;
   b.ktiles_per = (int)cdiv64(T, 64);

@@ -34,3 +34,63 @@ extern "C" int vj_probe_copy(const void* src, void* dst, int64_t bytes, hipStrea
   VJ_LAUNCH_CHECK("vj_probe_copy");
   return 0;
 }
+
+// LDS read throughput of one CU with 8 waves issuing back-to-back reads (no MFMA, no global traffic):
+// mode 0 = ds_read_b128 (lane-linear, conflict-free), 1 = ds_read_b64_tr_b16 with the TN GEMM's fragment addressing
+// (gemm8_tn.hip: 256-byte token rows, chunk ^ ((row & 7) << 1)), 2 = ds_read_b64 (lane-linear).
+// out[wave] = cycles for iters x 8 reads; bytes/clk/CU = 8 waves * iters * 8 * 64 lanes * {16, 8, 8} / max cycles.
+template <int MODE>
+__global__ __launch_bounds__(512) void probe_lds_bw_kernel(long long* out, int iters) {
+  extern __shared__ char probe_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < 128 * 1024 / 4; i += 512) ((uint32_t*)probe_lds)[i] = i;
+  __syncthreads();
+  unsigned addr;
+  if (MODE == 1) {
+    const int g = lane >> 4, jj = (lane & 15) >> 2, q4 = lane & 3;
+    const int row_l = 4 * g + jj, key2 = (row_l & 7) << 1;
+    addr = (unsigned)(uintptr_t)probe_lds + w * 16384 + row_l * 256 + (q4 & 1) * 8 + ((((w & 3) * 4) ^ key2) | (q4 >> 1)) * 16;
+  } else {
+    addr = (unsigned)(uintptr_t)probe_lds + w * 16384 + lane * (MODE == 0 ? 16 : 8);
+  }
+  uint32_t sink = 0;
+  const long long t0 = clock64();
+  for (int it = 0; it < iters; it++) {
+    if (MODE == 0) {
+      u32x4_t r[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[k]) : "v"(addr), "n"(1024 * 0) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 8; k++) sink ^= r[k][0];
+    } else {
+      u32x2_t r[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (MODE == 1) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r[k]) : "v"(addr) : "memory");
+        else asm volatile("ds_read_b64 %0, %1" : "=v"(r[k]) : "v"(addr) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 8; k++) sink ^= r[k][0];
+    }
+  }
+  const long long t1 = clock64();
+  if (lane == 0) out[blockIdx.x * 8 + w] = t1 - t0;
+  if (sink == 0x12345678u) out[0] = 0;
+}
+extern "C" int vj_probe_lds_bw(long long* out, int mode, int iters, int n_wgs, hipStream_t stream) {
+  VJ_CHECK_ARG(mode >= 0 && mode <= 2 && iters > 0 && n_wgs > 0, "vj_probe_lds_bw: bad arguments");
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute((const void*)probe_lds_bw_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)probe_lds_bw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void*)probe_lds_bw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return true;
+  }();
+  (void)attr_set;
+  if (mode == 0) hipLaunchKernelGGL(probe_lds_bw_kernel<0>, dim3(n_wgs), dim3(512), 128 * 1024, stream, out, iters);
+  else if (mode == 1) hipLaunchKernelGGL(probe_lds_bw_kernel<1>, dim3(n_wgs), dim3(512), 128 * 1024, stream, out, iters);
+  else hipLaunchKernelGGL(probe_lds_bw_kernel<2>, dim3(n_wgs), dim3(512), 128 * 1024, stream, out, iters);
+  VJ_LAUNCH_CHECK("vj_probe_lds_bw");
+  return 0;
+}

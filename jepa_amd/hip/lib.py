@@ -104,6 +104,7 @@ SIGNATURES = {
     "vj_get_option": (I32, [ctypes.c_char_p, ctypes.POINTER(I32)]),
     "vj_probe_tr16": (I32, [P, I32, P]),
     "vj_probe_copy": (I32, [P, P, I64, P]),
+    "vj_probe_lds_bw": (I32, [P, I32, I32, I32, P]),
 }
 
 
