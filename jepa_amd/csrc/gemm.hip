@@ -288,6 +288,9 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     const int use_4w = vj_opt(VJ_OPT_GEMM_4W);
     if (use_4w == 1 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 64)
       return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
+    // 2: only where a 256-wide tile wastes a third of its columns (N = 384: the predictor's proj / fc2 / dgrad outputs)
+    if (use_4w == 2 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 64 && a.N % 256 == 128 && a.N < 512)
+      return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
     if (!is_wgrad && a.K % 64 == 0 && t256 >= 90) pipe = 3;
     if (is_wgrad && a.K % 64 == 0 && t256 >= 40) pipe = 3;   // qkv/fc1/fc2 wgrads: 8-phase + split-K (0.97-1.08 vs 0.78-0.96 PF)

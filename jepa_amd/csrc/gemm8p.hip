@@ -359,8 +359,8 @@ template <int EPI>
 static bool persist_ok(const GemmArgs& a, int ncu) {
   if (EPI == EPI_F32) return false;
   if (a.M < 256 || a.N < 256 || a.K % 64 != 0 || a.K < 256) return false;
-  const int64_t tiles = cdiv64(a.M, 256) * cdiv64(a.N, 256);
-  if (tiles <= ncu) return false;                                   // one round: nothing to overlap
+  // (single-round shapes, tiles <= CUs, come here too: nothing to overlap across tiles, but this kernel's issue path is
+  //  leaner than gemm8.hip's -- SQ_INSTS_SALU / SQ_INSTS_MFMA 0.46 vs 0.96 -- : -0.71 ms/step, profiles/r03_abab_persist_small.md)
   if (a.N % 8 != 0 || a.ldc % 8 != 0 || ((uintptr_t)a.C & 15) != 0) return false;
   if (EPI == EPI_GELU && a.aux_out != nullptr && (a.ldaux % 8 != 0 || ((uintptr_t)a.aux_out & 15) != 0)) return false;
   if (a.lda >= (1 << 23) || a.ldb >= (1 << 23)) return false;            // 32-bit per-lane byte offsets

@@ -9,8 +9,10 @@
 enum VjOpt {
   VJ_OPT_GEMM_FWD_FLAGS = 0,   // vj_gemm_bf16_nt flags for the chains' forward GEMMs (0 = automatic selection)
   VJ_OPT_GEMM_DGRAD_FLAGS,     // ... for the chains' dgrad GEMMs
-  VJ_OPT_GEMM_4W,              // 1: every forward / dgrad GEMM on the 4-wave 256x128 kernel; 2: per-shape policy
-  VJ_OPT_GEMM_PERSIST,         // 1 (default): persistent 8-phase kernel (gemm8p.hip) where it applies, trimmed grid; 2: one
+  VJ_OPT_GEMM_4W,              // 1: every forward / dgrad GEMM on the 4-wave 256x128 kernel; 2: only N = 384 outputs (a 256-wide
+                               // tile wastes a third there; -0.10 ms/step, 6 of 6 rounds: profiles/r03_abab_n384_policy.md)
+  VJ_OPT_GEMM_PERSIST,         // 1 (default): persistent 8-phase kernel (gemm8p.hip) where it applies (single-round shapes
+                               // included), trimmed grid; 2: one
                                // workgroup per CU; 0: always one tile per workgroup (gemm8.hip)
   VJ_OPT_WGRAD_LANES,          // weight-gradient lanes of vj_blocks_bwd (1 or 2)
   VJ_OPT_WGRAD_TN,             // 1 (default): transpose-free weight gradients (gemm8_tn.hip); 0: transposes + NT GEMM
