@@ -363,8 +363,8 @@ def main():
                     break
         roof = {"bound": "mfma",
                 "kernel": "bf16 MFMA GEMM family (gemm_nt_8phase_persist_kernel: persistent 256x256 staggered 8-phase, "
-                          "cross-tile LDS-DMA prefetch; gemm_nt_8phase_kernel for <= 256-tile problems; gemm_tn_8phase_kernel: "
-                          "transpose-free split-K weight gradients; MFMA 16x16x32); traffic = dominant kernel "
+                          "cross-tile LDS-DMA prefetch; gemm_tn_8phase_kernel: transpose-free weight gradients, the four of a "
+                          "block in one launch; MFMA 16x16x32); traffic = dominant kernel "
                           "gemm_nt_8phase_persist_kernel<0>",
                 "achieved": round(ach / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",

@@ -43,18 +43,24 @@ static inline int64_t pad64i(int64_t m) { return (m + 63) / 64 * 64; }
 // so an event may be re-recorded as soon as its wait has been enqueued, which always happens inside the same chain call.
 namespace {
 constexpr int POOL = 1024;
-hipEvent_t g_pool[POOL];
-std::once_flag g_pool_once;
-std::atomic<unsigned> g_pool_next{0};
-bool g_pool_ok = false;
+struct EventPool {   // one per device: an event belongs to the device that was current when it was created
+  hipEvent_t ev[POOL];
+  std::once_flag once;
+  std::atomic<unsigned> next{0};
+  bool ok = false;
+};
+EventPool g_pools[VJ_MAX_DEVICES];
+thread_local bool g_pool_ok = false;   // of the pool this thread used last (read right after next_event())
 
 hipEvent_t next_event() {
-  std::call_once(g_pool_once, [] {
-    g_pool_ok = true;
+  EventPool& P = g_pools[vj_device_slot()];
+  std::call_once(P.once, [&P] {
+    P.ok = true;
     for (int i = 0; i < POOL; i++)
-      if (hipEventCreateWithFlags(&g_pool[i], hipEventDisableTiming) != hipSuccess) g_pool_ok = false;
+      if (hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming) != hipSuccess) P.ok = false;
   });
-  return g_pool[g_pool_next.fetch_add(1) % POOL];
+  g_pool_ok = P.ok;
+  return P.ev[P.next.fetch_add(1) % POOL];
 }
 
 // `to` waits for everything enqueued so far on `from`
@@ -287,7 +293,7 @@ static BwdLayout bwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
   L.ln_ws = take(L.ln_ws_bytes);
   L.tcs_ws_bytes = vj_transpose_colsum_ws_bytes(M, nmax);
   if (vj_colsum_ws_bytes(nmax) > L.tcs_ws_bytes) L.tcs_ws_bytes = vj_colsum_ws_bytes(nmax);
-  for (int w = 0; w < 2; w++) {   // one set per weight-gradient lane (see SideCtx)
+  for (int w = 0; w < 1; w++) {   // scratch of the weight-gradient stream
     L.dyT[w] = take(nmax * Mp * 2);
     L.xT[w] = take(Dh * Mp * 2);
     L.tcs_ws[w] = take(L.tcs_ws_bytes);
@@ -301,22 +307,8 @@ extern "C" int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int6
   return bwd_layout(M, D, Dh, heads).total;
 }
 
-// A second, library-owned lane for the weight gradients (VJ_WGRAD_LANES=2): fc2 / proj go to the caller's side stream,
-// fc1 / qkv to the lane; each lane is a dependent chain of small kernels (transpose, transpose, GEMM, slice reduction,
-// bias reduction), two of them fill each other's launch gaps.  The lane is joined into `side` at the end of every block,
-// so the caller still sees ONE producer stream.
-static hipStream_t g_lane2 = nullptr;
-static hipStream_t lane2() {
-  static std::once_flag once;
-  std::call_once(once, [] {
-    if (hipStreamCreateWithFlags(&g_lane2, hipStreamNonBlocking) != hipSuccess) g_lane2 = nullptr;
-  });
-  return g_lane2;
-}
-
 struct SideCtx {
   hipStream_t main, side;   // side == main: serial mode
-  hipStream_t side2;        // second weight-gradient lane or nullptr
   char* tmp;
   const BwdLayout* L;
   int64_t M;
@@ -325,12 +317,12 @@ struct SideCtx {
 };
 
 // dW (fp32, += beta*old) = alpha * dy^T x_in ; db = alpha * colsum(dy) -- on the side stream, after `main` produced dy
-static int wgrad(const SideCtx& c, const void* dy, const void* x_in, const vj_linear_t& lw_in, int lane = 0, bool bias_done = false) {
+static int wgrad(const SideCtx& c, const void* dy, const void* x_in, const vj_linear_t& lw_in, bool bias_done = false) {
+  constexpr int lane = 0;   // one weight-gradient stream, one set of scratch buffers
   vj_linear_t lw = lw_in;
   if (bias_done) lw.gb = nullptr;   // the bias gradient (column sum of dy) came out of the LayerNorm backward that produced dy
   const int64_t M = c.M, Mp = pad64i(M), N = lw.n_out, K = lw.k_in;
-  if (lane == 1 && c.side2 == nullptr) lane = 0;
-  hipStream_t st = lane == 1 ? c.side2 : c.side;
+  hipStream_t st = c.side;
   if (st != c.main) CH(stream_after(st, c.main, "vj_blocks_bwd(fork)"));
   if (c.tn && N % 8 == 0 && K % 8 == 0) {
     if (lw.gb) CH(vj_colsum_bf16(dy, M, N, N, M > 0 ? M : 1, 0, M > 0 ? M : 1, lw.gb, c.alpha, c.beta, c.tmp + c.L->tcs_ws[lane],
@@ -404,7 +396,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
   }
   const char* sv = (const char*)save_ws;
   char* tmp = (char*)tmp_ws;
-  SideCtx sc{stream, side ? side : stream, (side && vj_opt(VJ_OPT_WGRAD_LANES) >= 2) ? lane2() : nullptr, tmp, &L, M, alpha, beta_acc, ((flags & 1) || vj_opt(VJ_OPT_WGRAD_TN)) ? 1 : 0};
+  SideCtx sc{stream, side ? side : stream, tmp, &L, M, alpha, beta_acc, ((flags & 1) || vj_opt(VJ_OPT_WGRAD_TN)) ? 1 : 0};
   constexpr int MAX_BLOCKS = 256;
   VJ_CHECK_ARG(n_blocks <= MAX_BLOCKS, "vj_blocks_bwd: more than %d blocks", MAX_BLOCKS);
   hipEvent_t side_done[MAX_BLOCKS];
@@ -428,17 +420,17 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
                                 {du, w + F.y2, &b.fc1, false},
                                 {dx1, w + F.o, &b.proj, fuse_cs},
                                 {dqkv, w + F.y1, &b.qkv, false}};
-    if (!grouped) CH(wgrad(sc, dx2, w + F.g, b.fc2, 0, fuse_cs && li + 1 < n_blocks));
+    if (!grouped) CH(wgrad(sc, dx2, w + F.g, b.fc2, fuse_cs && li + 1 < n_blocks));
     CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream, g_dgrad_flags));
     // fc1
-    if (!grouped) CH(wgrad(sc, du, w + F.y2, b.fc1, 1));
+    if (!grouped) CH(wgrad(sc, du, w + F.y2, b.fc1));
     CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     // dx1 is the dY of proj: its bias gradient = column sums of dx1, produced by this pass
     CH(vj_layernorm_bwd_colsum(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
                                dx1, b.norm2.gg, b.norm2.gb, fuse_cs ? b.proj.gb : nullptr, alpha, beta_acc, M, D,
                                tmp + L.ln_ws, L.ln_ws_bytes, stream));
     // proj
-    if (!grouped) CH(wgrad(sc, dx1, w + F.o, b.proj, 0, fuse_cs));
+    if (!grouped) CH(wgrad(sc, dx1, w + F.o, b.proj, fuse_cs));
     CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     for (int64_t s = 0; s < n_segs; s++) {
       const vj_seg_t& sg = segs[s];
@@ -450,14 +442,13 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     }
     // qkv
     if (grouped) CH(wgrad_group(sc, items, 4));
-    else CH(wgrad(sc, dqkv, w + F.y1, b.qkv, 1));
+    else CH(wgrad(sc, dqkv, w + F.y1, b.qkv));
     CH(gemm(dqkv, 3 * D, b.qkv.wT, b.qkv.ldwT, tmp + L.dy1, D, M, D, 3 * D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0,
             stream, g_dgrad_flags));
     // dx is the dY of the previous block's fc2 (its dx2): that bias gradient comes out of this pass
     CH(vj_layernorm_bwd_colsum(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
                                b.norm1.gg, b.norm1.gb, (fuse_cs && li > 0) ? blocks[li - 1].fc2.gb : nullptr, alpha, beta_acc,
                                M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
-    if (sc.side2) CH(stream_after(sc.side, sc.side2, "vj_blocks_bwd(lane join)"));
     if (sc.side != sc.main) {
       hipEvent_t e = next_event();
       HIPCH(hipEventRecord(e, sc.side), "vj_blocks_bwd");

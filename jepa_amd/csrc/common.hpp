@@ -105,6 +105,30 @@ __device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {
   return __builtin_elementwise_fma(x * c, g, phi);
 }
 
+// ---- per-device one-time setup ------------------------------------------------------------------------------------
+// Function attributes (dynamic LDS limit), event pools and small constant buffers belong to a DEVICE, not to the process:
+// a host that drives several GPUs from one process (not this package's own launcher: one process per GPU) calls the C ABI
+// with different current devices.  vj_device_slot() = current HIP device (0 on error); VjPerDeviceOnce runs an idempotent
+// setup once per device (a lost race repeats it harmlessly).
+#include <atomic>
+#define VJ_MAX_DEVICES 64
+inline int vj_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev % VJ_MAX_DEVICES;
+}
+struct VjPerDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  template <class F>
+  void operator()(F&& f) {
+    const unsigned long long bit = 1ull << vj_device_slot();
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      f();
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+};
+
 // ---- host side error plumbing (no C++ exception crosses the C ABI) ----
 extern "C" const char* vj_last_error(void);
 void vj_set_error(const char* fmt, ...);

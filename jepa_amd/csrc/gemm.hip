@@ -220,12 +220,11 @@ template <int BK, int NS, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
   constexpr int smem = NS * (BM + BN) * BK * 2;
   // function-local static with an initialiser: set exactly once, thread-safe (the C ABI is re-entrant)
-  static const bool attr_set = [] {
+  static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
+  attr_once([] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, NS, EPI, GLDS, BM, BN, WM, WN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    return true;
-  }();
-  (void)attr_set;
+  });
   GemmArgs b = a;
   b.tiles_m = (int)cdiv64(a.M, BM);
   b.tiles_n = (int)cdiv64(a.N, BN);

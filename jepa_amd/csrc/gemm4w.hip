@@ -307,11 +307,10 @@ __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, in
 template <int EPI>
 static int launch4w(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
   constexpr int smem = W4_SLOTS * W4_PART;
-  static const bool attr_set = [] {
+  static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
+  attr_once([] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_4w_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    return true;
-  }();
-  (void)attr_set;
+  });
   static const bool occ_dbg = [] {
     if (getenv("VJ_GEMM_DBG_OCC")) {
       int n = -1;

@@ -302,11 +302,10 @@ template <int EPI>
 static int launch8(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
   constexpr int smem = 8 * PART_BYTES;
   // function-local static with an initialiser: set exactly once, thread-safe (the C ABI is re-entrant)
-  static const bool attr_set = [] {
+  static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
+  attr_once([] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_8phase_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    return true;
-  }();
-  (void)attr_set;
+  });
   GemmArgs b = a;
   b.tiles_m = (int)cdiv64(a.M, P8_BM);
   b.tiles_n = (int)cdiv64(a.N, P8_BN);

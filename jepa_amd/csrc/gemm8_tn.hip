@@ -359,23 +359,26 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
                                          slice);
 }
 
-bf16_t* g_zero_row = nullptr;   // 128 bf16 zeros (one process drives one GPU)
+bf16_t* g_zero_rows[VJ_MAX_DEVICES] = {};   // 128 bf16 zeros, one buffer per device
 
 }  // namespace
 
 __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, int64_t N, int64_t ldc, int S,
                                      float alpha, float beta);   // gemm.hip
 
-static int tn_zero_row() {
-  if (g_zero_row == nullptr) {
-    hipError_t e = hipMalloc((void**)&g_zero_row, 256);
-    if (e == hipSuccess) e = hipMemset(g_zero_row, 0, 256);
+static int tn_zero_row(const bf16_t** out) {
+  bf16_t*& z = g_zero_rows[vj_device_slot()];
+  if (z == nullptr) {
+    bf16_t* q = nullptr;
+    hipError_t e = hipMalloc((void**)&q, 256);
+    if (e == hipSuccess) e = hipMemset(q, 0, 256);
     if (e != hipSuccess) {
       vj_set_error("vj_gemm_bf16_tn_splitk: zero row allocation failed: %s", hipGetErrorString(e));
-      g_zero_row = nullptr;
       return (int)e;
     }
+    z = q;
   }
+  *out = z;
   return 0;
 }
 
@@ -401,7 +404,7 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
   b.tiles_m = (int)cdiv64(N1, 256);
   b.tiles_n = (int)cdiv64(N2, 256);
   b.dbg = vj_opt(VJ_OPT_WGRAD_SLOW_ISSUE) ? 8 : 0;   // A/B switch of the K loop's issue path
-  b.zero_row = g_zero_row;
+  b.zero_row = nullptr;   // set by the caller (tn_zero_row)
   b.splitk = 1;
   b.ktiles_per = (int)cdiv64(T, 64);
   b.ws = nullptr;
@@ -418,12 +421,11 @@ static void tn_reduce(const GemmArgs& b, float alpha, float beta, hipStream_t st
 
 template <bool GROUPED>
 static void tn_set_attr() {
-  static const bool attr_set = [] {   // function-local static with an initialiser: set exactly once, thread-safe
+  static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
+  attr_once([] {
     (void)hipFuncSetAttribute((const void*)gemm_tn_8phase_kernel<GROUPED>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               8 * TN_PART_BYTES);
-    return true;
-  }();
-  (void)attr_set;
+  });
 }
 
 // dW[N1,N2] = alpha * dY[T,N1]^T X[T,N2] + beta * dW.  (backward of every nn.Linear on the path)
@@ -434,11 +436,13 @@ extern "C" int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X
   if (N1 == 0 || N2 == 0) return 0;
   if (int rc = tn_check("vj_gemm_bf16_tn_splitk", dY, ldy, X, ldx, dW, ldw, T, N1, N2)) return rc;
   VJ_CHECK_ARG(ws != nullptr && ws_bytes >= N1 * N2 * 4, "vj_gemm_bf16_tn_splitk: workspace must hold at least N1*N2 fp32");
-  if (int rc = tn_zero_row()) return rc;
+  const bf16_t* zero_row = nullptr;
+  if (int rc = tn_zero_row(&zero_row)) return rc;
   tn_set_attr<false>();
   TnSingleArgs a;
   GemmArgs& b = a.g;
   b = tn_args(dY, ldy, X, ldx, dW, ldw, T, N1, N2, alpha, beta);
+  b.zero_row = zero_row;
   const int nk = (int)cdiv64(T, 64);
   b.splitk = pick_splitk((int64_t)b.tiles_m * b.tiles_n, nk, 256, 1.45, 8, N1, N2, ws_bytes);
   b.ws = (float*)ws;
@@ -484,8 +488,9 @@ extern "C" int vj_gemm_bf16_tn_grouped(const void* probs_v, int64_t n, int64_t T
     a.n++;
   }
   if (a.n == 0) return 0;
-  if (int rc = tn_zero_row()) return rc;
-  for (int i = 0; i < a.n; i++) a.g[i].zero_row = g_zero_row;
+  const bf16_t* zero_row = nullptr;
+  if (int rc = tn_zero_row(&zero_row)) return rc;
+  for (int i = 0; i < a.n; i++) a.g[i].zero_row = zero_row;
   VJ_CHECK_ARG(ws != nullptr && ws_bytes >= out_elems * 4, "vj_gemm_bf16_tn_grouped: workspace must hold at least sum N1*N2 fp32");
   const int nk = (int)cdiv64(T, 64);
   // one split factor for the group: pick_splitk's cost model on the summed tile count / output size

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
   }
 }
 
-int g_num_cus = 0;
+int g_num_cus = 0;   // CU count of the (homogeneous) GPUs of this node, read once
 
 }  // namespace
 
@@ -380,11 +380,10 @@ static bool persist_ok(const GemmArgs& a, int ncu) {
 template <int EPI>
 static int launch8p(const GemmArgs& a, hipStream_t stream) {
   constexpr int smem = PP_RING + 8 * PP_STAGE_PER_WAVE;   // 160 KB: the whole LDS of a CU
-  static const bool attr_set = [] {
+  static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
+  attr_once([] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_8phase_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    return true;
-  }();
-  (void)attr_set;
+  });
   GemmArgs b = a;
   b.tiles_m = (int)cdiv64(a.M, 256);
   b.tiles_n = (int)cdiv64(a.N, 256);

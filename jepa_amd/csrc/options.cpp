@@ -13,7 +13,7 @@ struct OptDef {
   int dflt;
 };
 const OptDef kDefs[VJ_OPT_COUNT] = {
-    {"gemm_fwd_flags", 0}, {"gemm_dgrad_flags", 0}, {"gemm_4w", 0},         {"gemm_persist", 1}, {"wgrad_lanes", 1},
+    {"gemm_fwd_flags", 0}, {"gemm_dgrad_flags", 0}, {"gemm_4w", 0},         {"gemm_persist", 1},
     {"wgrad_tn", 1},       {"wgrad_group", 1},      {"wgrad_slow_issue", 0}, {"gemm_dbg", 0},
 };
 std::atomic<int> g_val[VJ_OPT_COUNT];

@@ -14,7 +14,6 @@ enum VjOpt {
   VJ_OPT_GEMM_PERSIST,         // 1 (default): persistent 8-phase kernel (gemm8p.hip) where it applies (single-round shapes
                                // included), trimmed grid; 2: one
                                // workgroup per CU; 0: always one tile per workgroup (gemm8.hip)
-  VJ_OPT_WGRAD_LANES,          // weight-gradient lanes of vj_blocks_bwd (1 or 2)
   VJ_OPT_WGRAD_TN,             // 1 (default): transpose-free weight gradients (gemm8_tn.hip); 0: transposes + NT GEMM
   VJ_OPT_WGRAD_GROUP,          // 1 (default): the four weight gradients of a block in ONE launch (vj_gemm_bf16_tn_grouped);
                                // 0: one launch each (different fp32 summation order: results agree to rounding, not bitwise)

@@ -81,13 +81,12 @@ __global__ __launch_bounds__(512) void probe_lds_bw_kernel(long long* out, int i
 }
 extern "C" int vj_probe_lds_bw(long long* out, int mode, int iters, int n_wgs, hipStream_t stream) {
   VJ_CHECK_ARG(mode >= 0 && mode <= 2 && iters > 0 && n_wgs > 0, "vj_probe_lds_bw: bad arguments");
-  static const bool attr_set = [] {
+  static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
+  attr_once([] {
     (void)hipFuncSetAttribute((const void*)probe_lds_bw_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)probe_lds_bw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void*)probe_lds_bw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return true;
-  }();
-  (void)attr_set;
+  });
   if (mode == 0) hipLaunchKernelGGL(probe_lds_bw_kernel<0>, dim3(n_wgs), dim3(512), 128 * 1024, stream, out, iters);
   else if (mode == 1) hipLaunchKernelGGL(probe_lds_bw_kernel<1>, dim3(n_wgs), dim3(512), 128 * 1024, stream, out, iters);
   else hipLaunchKernelGGL(probe_lds_bw_kernel<2>, dim3(n_wgs), dim3(512), 128 * 1024, stream, out, iters);
