@@ -42,6 +42,11 @@ __device__ __forceinline__ unsigned lds_addr(const char* p) {
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(gsrc) : "memory");
 }
+// the same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: no 64-bit vector address
+// arithmetic per instruction (the attention kernels are bound by VALU issue)
+__device__ __forceinline__ void dma16_sv(const void* sbase, unsigned voff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -157,7 +162,8 @@ struct TileDma {
   using RT = RowTile<HDP, NT>;
   static_assert(RT::CAN_FULL, "tile items must be a multiple of the workgroup size");
   static constexpr int NDMA = RT::NIT;
-  int row[NDMA], col[NDMA];
+  int row[NDMA];
+  unsigned col2[NDMA];   // byte offset of the (swizzled, clamped) source chunk inside a row
   int wu;
   __device__ __forceinline__ TileDma(int tid, int hd) {
     wu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,19 +172,25 @@ struct TileDma {
       const int item = tid + it * NT;
       const int r = item / RT::CHP, c = (item % RT::CHP) ^ rm_swz<HDP>(r);
       row[it] = r;
-      col[it] = c * 8 < hd ? c * 8 : 0;
+      col2[it] = (unsigned)(c * 8 < hd ? c * 8 : 0) * 2u;
     }
   }
+  // wave-uniform tile bases in SGPRs + 32-bit per-lane byte offsets (row * row stride + chunk): no 64-bit vector address
+  // arithmetic (these kernels are bound by VALU issue)
   template <bool FULL>
   __device__ __forceinline__ void issue(const bf16_t* xb, int64_t rsx, const bf16_t* yb, int64_t rsy, int r0, int nrows,
                                         char* buf) const {
+    const bf16_t* xt = xb + (int64_t)r0 * rsx;   // uniform
+    const bf16_t* yt = yb + (int64_t)r0 * rsy;
+    const unsigned rsx2 = (unsigned)rsx * 2u, rsy2 = (unsigned)rsy * 2u;
+    const int last = nrows - 1 - r0;              // >= 0: the tile exists
 #pragma unroll
     for (int it = 0; it < NDMA; it++) {
-      int r = r0 + row[it];
-      if constexpr (!FULL) r = r < nrows ? r : nrows - 1;
+      int r = row[it];
+      if constexpr (!FULL) r = r < last ? r : last;
       char* dst = buf + (it * NT + wu * 64) * 16;   // wave-uniform; the hardware adds lane * 16
-      dma16(xb + (int64_t)r * rsx + col[it], lds_addr(dst));
-      dma16(yb + (int64_t)r * rsy + col[it], lds_addr(dst + RT::BYTES));
+      dma16_sv(xt, (unsigned)r * rsx2 + col2[it], lds_addr(dst));
+      dma16_sv(yt, (unsigned)r * rsy2 + col2[it], lds_addr(dst + RT::BYTES));
     }
   }
 };
@@ -247,7 +259,8 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
   // per-lane source of DMA item it: row (item / CHP) of the tile, chunk (item % CHP) ^ swizzle(row); chunks beyond
   // the real head dimension re-read chunk 0 (they only meet zero Q chunks / produce discarded O columns) and rows
   // beyond S re-read row S-1 (their scores are masked to -inf, P = 0): the DMA never needs a zero fill.
-  int dma_row[NDMA], dma_off[NDMA];
+  int dma_row[NDMA];
+  unsigned dma_voff[NDMA], dma_col2[NDMA];   // byte offsets inside a tile: (row * rs + col) * 2 and col * 2
   const bool dma_on = RT::CAN_FULL || tid < 64 * RT::CHP;
 #pragma unroll
   for (int it = 0; it < NDMA; it++) {
@@ -255,27 +268,32 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
     const int row = item / RT::CHP, c = (item % RT::CHP) ^ rm_swz<HDP>(row);
     const int col = c * 8 < hd ? c * 8 : 0;
     dma_row[it] = row;
-    dma_off[it] = row * (int)rs + col;
+    dma_col2[it] = (unsigned)col * 2u;
+    dma_voff[it] = ((unsigned)row * (unsigned)rs + (unsigned)col) * 2u;
   }
   const int64_t v_off = (int64_t)H * hd;
   const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned rs2 = (unsigned)rs * 2u;
+  // wave-uniform tile base (SGPRs) + 32-bit per-lane offset: the steady state spends no vector instruction on addresses
   auto issue = [&](const int tile, const int buf_off, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     char* kb = smem + buf_off;
+    const bf16_t* kt = kbase + (int64_t)tile * 64 * rs;   // uniform
+    const bf16_t* vt = kt + v_off;
 #pragma unroll
     for (int it = 0; it < NDMA; it++) {
-      const bf16_t* ks;
+      unsigned vo;
       if constexpr (FULL) {
-        ks = kbase + (int64_t)tile * 64 * rs + dma_off[it];
+        vo = dma_voff[it];
       } else {
-        int r = tile * 64 + dma_row[it];
-        r = r < S ? r : S - 1;
-        ks = kbase + (int64_t)r * rs + (dma_off[it] - dma_row[it] * (int)rs);
+        const int last = S - 1 - tile * 64;                     // >= 0: the tile exists
+        const int r = dma_row[it] < last ? dma_row[it] : last;  // rows beyond S re-read row S-1
+        vo = (unsigned)r * rs2 + dma_col2[it];
       }
       char* dst = kb + (it * NT + wu * 64) * 16;   // wave-uniform; the hardware adds lane * 16
       if (dma_on) {
-        dma16(ks, lds_addr(dst));
-        dma16(ks + v_off, lds_addr(dst + RT::BYTES));
+        dma16_sv(kt, vo, lds_addr(dst));
+        dma16_sv(vt, vo, lds_addr(dst + RT::BYTES));
       }
     }
   };
