@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
   // barrier per tile
   constexpr int BUFB = 2 * RowTile<HDP>::BYTES;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUFB + 2 * 2 * 64 * 4];
-  float* stat = (float*)(smem + 2 * BUFB);   // [buffer][lse 0..63 | delta 0..63]
+  float* stat = (float*)(smem + 2 * BUFB);   // [buffer][lse 0..63 | -delta 0..63]
   const TrFrag<HDP> trf(threadIdx.x & 63);
   constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
     if (tid < 64) {
       const int q = r0 + tid;
       lse_r = q < S ? lse_b[q] : INFINITY;  // +inf -> P = 0 for padded query rows (their Q / dO rows re-read row S-1)
-      dl_r = q < S ? dl_b[q] : 0.f;
+      dl_r = q < S ? -dl_b[q] : 0.f;        // NEGATED: it seeds the dP accumulator
     }
   };
   __builtin_amdgcn_s_waitcnt(0x0f70);   // compiler-visible vmcnt(0): the K / V fragment loads are complete
@@ -529,7 +529,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
     float pv[4][4], dsv[4][4];
 #pragma unroll
     for (int qt = 0; qt < 4; qt++) {
-      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {0.f, 0.f, 0.f, 0.f};
+      const float4 lse4 = *(const float4*)(lse_s + qt * 16 + 4 * g);   // queries qt*16 + 4g + {0..3}
+      const float4 ndl4 = *(const float4*)(dl_s + qt * 16 + 4 * g);    // -delta of the same queries
+      // the dP accumulator STARTS at -delta[q] (this lane's four rows): dP - delta comes out of the matrix pipe, the
+      // kernel is bound by vector issue
+      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {ndl4.x, ndl4.y, ndl4.z, ndl4.w};
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) {
         const bf16x8_t qa = RowTile<HDP>::frag(q_lds, qt * 16 + li, ks * 4 + g);
@@ -537,15 +541,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
         sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc, 0, 0, 0);
         dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc, 0, 0, 0);
       }
-      const float4 lse4 = *(const float4*)(lse_s + qt * 16 + 4 * g);   // queries qt*16 + 4g + {0..3}
-      const float4 dl4 = *(const float4*)(dl_s + qt * 16 + 4 * g);
-      const f32x2_t nl[2] = {{-lse4.x, -lse4.y}, {-lse4.z, -lse4.w}}, dl2[2] = {{dl4.x, dl4.y}, {dl4.z, dl4.w}};
+      const f32x2_t nl[2] = {{-lse4.x, -lse4.y}, {-lse4.z, -lse4.w}};
 #pragma unroll
-      for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+      for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
         const f32x2_t sv = {sacc[2 * hf], sacc[2 * hf + 1]}, dpv = {dpacc[2 * hf], dpacc[2 * hf + 1]};
         const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl[hf]);   // padded queries: lse = +inf -> P = 0
         const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-        const f32x2_t ds = e * (dpv - dl2[hf]);
+        const f32x2_t ds = e * dpv;
         pv[qt][2 * hf] = e[0];
         pv[qt][2 * hf + 1] = e[1];
         dsv[qt][2 * hf] = ds[0];
@@ -658,6 +660,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) dqacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  f32x4_t ndl4[2];   // -delta[q] of this lane's query, four times: the seed of every dP accumulator block
+#pragma unroll
+  for (int qt = 0; qt < 2; qt++) ndl4[qt] = (f32x4_t){-dl_q[qt], -dl_q[qt], -dl_q[qt], -dl_q[qt]};
   const f32x2_t sc2 = {sc, sc};
   const int nt = (S + 63) / 64;
   const TileDma<HDP, 256> dma(tid, hd);
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
       for (int kt = 0; kt < 4; kt++) {
         sacc[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        dpacc[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        dpacc[qt][kt] = ndl4[qt];   // the dP accumulators start at -delta[q]: dP - delta comes out of the matrix pipe
       }
 #pragma unroll
     for (int kt = 0; kt < 4; kt++)
@@ -705,16 +710,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     // dS^T = P^T (dP^T - delta)
 #pragma unroll
     for (int qt = 0; qt < 2; qt++) {
-      const f32x2_t nl = {-lse_q[qt], -lse_q[qt]}, dl2 = {dl_q[qt], dl_q[qt]};
+      const f32x2_t nl = {-lse_q[qt], -lse_q[qt]};
 #pragma unroll
       for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-        for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+        for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
           const f32x2_t sv = {sacc[qt][kt][2 * hf], sacc[qt][kt][2 * hf + 1]};
           const f32x2_t dpv = {dpacc[qt][kt][2 * hf], dpacc[qt][kt][2 * hf + 1]};
           const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl);
           const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          const f32x2_t ds = e * (dpv - dl2);
+          const f32x2_t ds = e * dpv;
           sacc[qt][kt][2 * hf] = ds[0];
           sacc[qt][kt][2 * hf + 1] = ds[1];
         }

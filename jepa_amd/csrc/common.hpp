@@ -29,6 +29,13 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   bf2_t v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
+// the same, opaque to the optimiser: when only the UNPACKED halves of the result are used, hipcc otherwise converts each
+// element on its own (v_cvt_pk_bf16_f32 with a dummy partner) -- twice the conversions
+__device__ __forceinline__ uint32_t pack_bf2_opaque(float lo, float hi) {
+  uint32_t w = pack_bf2(lo, hi);
+  asm("" : "+v"(w));
+  return w;
+}
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -88,12 +95,21 @@ __device__ __forceinline__ void half_erfc2(f32x2_t x, f32x2_t& q, f32x2_t& gauss
   p = __builtin_elementwise_fma(p, t, c1);
   q = (p * t) * gauss;
 }
-// gelu(x) = x * Phi(x) = max(x, 0) - |x * q|
+// relu on the bit pattern: negative floats are negative integers (one v_max_i32; fmaxf() on a value that was assembled
+// from bits costs a second, canonicalising v_max_f32).  NaN passes through or becomes 0 -- the callers' inputs are finite.
+__device__ __forceinline__ float relu_bits(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
+}
+// gelu(x) = x * Phi(x) = max(x, 0) - |x * q|   (q = 0.5 erfc(|x|/sqrt2) >= 0; relative accuracy is kept in the negative tail)
+// (a single v_fma_f32 with -|x| as a source modifier would save half an instruction per element, but hipcc packs the two
+//  FMAs into a v_pk_fma_f32, which has no |x| modifier, and forcing the scalar form through inline assembly makes the
+//  one-pass epilogue of gemm8.hip spill 140 VGPRs)
 __device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
   f32x2_t q, g;
   half_erfc2(x, q, g);
   const f32x2_t h = x * q;
-  return (f32x2_t){fmaxf(x[0], 0.f) - fabsf(h[0]), fmaxf(x[1], 0.f) - fabsf(h[1])};
+  return (f32x2_t){relu_bits(x[0]) - fabsf(h[0]), relu_bits(x[1]) - fabsf(h[1])};
 }
 // gelu'(x) = Phi(x) + x * pdf(x),  Phi(x) = 0.5 + copysign(0.5 - q, x)
 __device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {

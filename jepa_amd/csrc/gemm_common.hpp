@@ -112,12 +112,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
       bf16_t* auxo = (EPI == EPI_GELU && HAS_OPT) ? p.aux_out + mc * p.ldaux : nullptr;
 #pragma unroll
       for (int j = 0; j < FN; j++) {
-        f32x2_t v01 = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y};
-        f32x2_t v23 = {acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+        f32x2_t v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
+        f32x2_t v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
         if constexpr (EPI == EPI_GELU) {
           u32x2_t u;
-          u[0] = pack_bf2(v01[0], v01[1]);
-          u[1] = pack_bf2(v23[0], v23[1]);
+          u[0] = pack_bf2_opaque(v01[0], v01[1]);
+          u[1] = pack_bf2_opaque(v23[0], v23[1]);
           if constexpr (HAS_OPT) {
             if (mok && cok[j]) *(u32x2_t*)(auxo + ncl[j]) = u;
           }
@@ -220,13 +220,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       }
 #pragma unroll
       for (int j = 0; j < FN; j++) {
-        f32x2_t v01 = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y};
-        f32x2_t v23 = {acc[i][j][2] + bias4[j].z, acc[i][j][3] + bias4[j].w};
+        f32x2_t v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
+        f32x2_t v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
         u32x2_t o;
         if constexpr (EPI == EPI_GELU) {
           u32x2_t u;
-          u[0] = pack_bf2(v01[0], v01[1]);
-          u[1] = pack_bf2(v23[0], v23[1]);
+          u[0] = pack_bf2_opaque(v01[0], v01[1]);
+          u[1] = pack_bf2_opaque(v23[0], v23[1]);
           // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
           v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
           v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
