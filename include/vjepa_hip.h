@@ -76,8 +76,10 @@ int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, const float
 /* ---- bf16 MFMA GEMM  C[M,N] = A[M,K] * B[N,K]^T (+ fused epilogue) ------------------------------------------
  * nn.Linear fwd/bwd (modules.py:31-34,63,76; predictor.py:194,237) and the Conv3d GEMM (patch_embed.py:56).
  * epilogue: 0 bf16 out = acc [+bias] [+residual]      (qkv / proj+residual / fc2+residual / dgrads)
- *           1 bf16 out = gelu(acc+bias), aux_out(nullable) = acc+bias    (fc1 + nn.GELU, modules.py:31-32)
- *           2 bf16 out = acc * gelu'(aux_in)           (fc2 dgrad fused with GELU backward)
+ *           1 bf16 out = gelu(u), u = bf16(acc+bias); aux_out(nullable) = bf16(gelu'(u))   (fc1 + nn.GELU, modules.py:31-32;
+ *             the derivative is saved INSTEAD of the pre-activation: it shares the erfc evaluation of the forward and is
+ *             the only thing the backward needs from u)
+ *           2 bf16 out = acc * aux_in, aux_in = what epilogue 1 saved   (fc2 dgrad fused with the GELU backward)
  *           3 fp32 out = alpha*acc + beta*C            (wgrad straight into the fp32 gradient arena)
  * K % 32 == 0, N % 4 == 0, lda/ldb % 8 == 0.  flags bit0: register-staged operand path (A/B testing). */
 int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,

@@ -10,7 +10,7 @@
 //
 // Saved-activation layout per block (workspace `save_ws`, everything 256-byte aligned, bf16 unless noted):
 //   x [M,D] (block input; block 0 uses the caller's x_in), y1 [M,D], qkv [M,3D], o [M,D], x1 [M,D], y2 [M,D],
-//   u [M,Dh] (pre-GELU), g [M,Dh], mean1 rstd1 mean2 rstd2 [M] fp32, lse2 [H*M] fp32 (per segment [B,H,S]).
+//   u [M,Dh] (gelu'(pre-activation): the saved GELU derivative), g [M,Dh], mean1 rstd1 mean2 rstd2 [M] fp32, lse2 [H*M] fp32 (per segment [B,H,S]).
 // With save = 0 (EMA target encoder, inference) one such set is reused by every block and x ping-pongs.
 #include "common.hpp"
 #include "options.hpp"

@@ -111,6 +111,19 @@ __device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
   const f32x2_t h = x * q;
   return (f32x2_t){relu_bits(x[0]) - fabsf(h[0]), relu_bits(x[1]) - fabsf(h[1])};
 }
+// gelu(x) AND gelu'(x) from one evaluation of the erfc core: the fc1 epilogue of a layer that will run backward stores
+// gelu'(u) (bf16) instead of the pre-activation u, and the fc2 dgrad epilogue only multiplies by it -- the backward never
+// re-evaluates exp / rcp / the polynomial (u has no other consumer)
+__device__ __forceinline__ void gelu_dgelu2(f32x2_t x, f32x2_t& y, f32x2_t& d) {
+  f32x2_t q, g;
+  half_erfc2(x, q, g);
+  const f32x2_t h = x * q;
+  y = (f32x2_t){relu_bits(x[0]) - fabsf(h[0]), relu_bits(x[1]) - fabsf(h[1])};   // = gelu2(x), bit for bit
+  const f32x2_t half = {0.5f, 0.5f}, a = half - q;
+  const f32x2_t phi = half + (f32x2_t){copysignf(a[0], x[0]), copysignf(a[1], x[1])};
+  const f32x2_t c = {0.3989422804014327f, 0.3989422804014327f};
+  d = __builtin_elementwise_fma(x * c, g, phi);                                    // = dgelu2(x), bit for bit
+}
 // gelu'(x) = Phi(x) + x * pdf(x),  Phi(x) = 0.5 + copysign(0.5 - q, x)
 __device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {
   f32x2_t q, g;

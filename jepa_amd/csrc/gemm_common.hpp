@@ -10,8 +10,8 @@ struct GemmArgs {
   void* C;
   const float* bias;      // [N] fp32, nullable
   const bf16_t* res;      // [M,N] bf16 residual, nullable (EPI_BF16)
-  const bf16_t* aux_in;   // [M,N] bf16 pre-activation u (EPI_DGELU)
-  bf16_t* aux_out;        // [M,N] bf16 pre-activation u out, nullable (EPI_GELU)
+  const bf16_t* aux_in;   // [M,N] bf16 saved GELU derivative gelu'(u) (EPI_DGELU): what EPI_GELU wrote to aux_out
+  bf16_t* aux_out;        // [M,N] bf16 gelu'(u) of the bf16-rounded pre-activation u = acc + bias, nullable (EPI_GELU)
   int64_t M, N, K, lda, ldb, ldc, ldr, ldaux;
   float alpha, beta;
   int tiles_m, tiles_n;
@@ -118,16 +118,23 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
           u32x2_t u;
           u[0] = pack_bf2_opaque(v01[0], v01[1]);
           u[1] = pack_bf2_opaque(v23[0], v23[1]);
+          // GELU (and, for a layer that will run backward, gelu') of the bf16-ROUNDED pre-activation
           if constexpr (HAS_OPT) {
-            if (mok && cok[j]) *(u32x2_t*)(auxo + ncl[j]) = u;
+            f32x2_t d01, d23;
+            gelu_dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
+            gelu_dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
+            u32x2_t dw;
+            dw[0] = pack_bf2(d01[0], d01[1]);
+            dw[1] = pack_bf2(d23[0], d23[1]);
+            if (mok && cok[j]) *(u32x2_t*)(auxo + ncl[j]) = dw;
+          } else {
+            v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+            v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
           }
-          // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
-          v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
-          v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
         } else if constexpr (EPI == EPI_DGELU) {
-          const u32x2_t u = opnd[i & 1][j];
-          v01 *= dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
-          v23 *= dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
+          const u32x2_t u = opnd[i & 1][j];   // saved gelu'(u)
+          v01 *= (f32x2_t){bf_lo(u[0]), bf_hi(u[0])};
+          v23 *= (f32x2_t){bf_lo(u[1]), bf_hi(u[1])};
         } else if constexpr (HAS_OPT) {
           const u32x2_t r2 = opnd[i & 1][j];
           v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
@@ -187,17 +194,24 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
   for (int par = 0; par < 2; par++) rd_off[par] = rrow * 128 + ((rch ^ ((par * 4 + (rrow >> 1)) & 7)) << 4);
   const bool col_ok = !EDGE || (n_base + rch * 8 < p.N);
 
-  auto flush = [&](bf16_t* out, int64_t ld, int row0) {   // LDS image -> global: (ds_read_b128 + 16-byte store) per 8 rows
+  constexpr bool HAS_OPND = (EPI == EPI_DGELU) || (EPI == EPI_BF16 && HAS_OPT);
+  constexpr bool TWO_OUT = (EPI == EPI_GELU) && HAS_OPT;
+  // 16-row blocks per pass.  Two outputs (GELU + saved derivative): half-size passes with BOTH images in the stage at once
+  // (blocks 0 .. RPP-1: the derivative, RPP .. 2 RPP-1: the GELU output) -- holding the second output in registers until the
+  // first is flushed costs 16 ... 64 VGPRs next to 128 live accumulators and made hipcc spill inside the K loop.
+  constexpr int RPP = TWO_OUT ? IPP / 2 : IPP;
+  static_assert(RPP >= 1 && FM % RPP == 0, "pass size");
+
+  // LDS image (RPP blocks starting at stage block `blk0`) -> global: (ds_read_b128 + 16-byte store) per 8 rows
+  auto flush = [&](bf16_t* out, int64_t ld, int row0, int blk0) {
 #pragma unroll
-    for (int it = 0; it < IPP * 2; it++) {
-      const u32x4_t v = *(const u32x4_t*)(stage + it * 1024 + rd_off[it & 1]);
+    for (int it = 0; it < RPP * 2; it++) {
+      const u32x4_t v = *(const u32x4_t*)(stage + blk0 * 2048 + it * 1024 + rd_off[it & 1]);
       const int64_t m = m_base + row0 + it * 8 + rrow;
       if (col_ok && (!EDGE || m < p.M)) *(u32x4_t*)(out + m * ld + n_base + rch * 8) = v;
     }
   };
 
-  constexpr bool HAS_OPND = (EPI == EPI_DGELU) || (EPI == EPI_BF16 && HAS_OPT);
-  constexpr bool TWO_OUT = (EPI == EPI_GELU) && HAS_OPT;
   const bf16_t* opnd_p = (EPI == EPI_DGELU) ? p.aux_in : p.res;
   const int64_t opnd_ld = (EPI == EPI_DGELU) ? p.ldaux : p.ldr;
   u32x2_t opnd[2][FN];
@@ -210,11 +224,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
   };
   if constexpr (HAS_OPND) load_row(0, opnd[0]);
 #pragma unroll
-  for (int ps = 0; ps < FM / IPP; ps++) {
-    u32x2_t second[TWO_OUT ? IPP : 1][FN];   // GELU outputs wait here (packed bf16) while the pre-activations go out
+  for (int ps = 0; ps < FM / RPP; ps++) {
 #pragma unroll
-    for (int ii = 0; ii < IPP; ii++) {
-      const int i = ps * IPP + ii;
+    for (int ii = 0; ii < RPP; ii++) {
+      const int i = ps * RPP + ii;
       if constexpr (HAS_OPND) {
         if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
       }
@@ -227,39 +240,35 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
           u32x2_t u;
           u[0] = pack_bf2_opaque(v01[0], v01[1]);
           u[1] = pack_bf2_opaque(v23[0], v23[1]);
-          // GELU of the bf16-rounded pre-activation: the backward pass re-derives gelu'(u) from the same bits
-          v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
-          v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
-          o[0] = pack_bf2(v01[0], v01[1]);
-          o[1] = pack_bf2(v23[0], v23[1]);
+          // GELU (and, for a layer that will run backward, gelu') of the bf16-ROUNDED pre-activation
           if constexpr (TWO_OUT) {
-            second[ii][j] = o;
-            o = u;
+            f32x2_t d01, d23;
+            gelu_dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
+            gelu_dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
+            u32x2_t dw;
+            dw[0] = pack_bf2(d01[0], d01[1]);
+            dw[1] = pack_bf2(d23[0], d23[1]);
+            *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = dw;   // the saved derivative: stage blocks 0 .. RPP-1
+          } else {
+            v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+            v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
           }
-        } else {
-          if constexpr (EPI == EPI_DGELU) {
-            const u32x2_t u = opnd[i & 1][j];
-            v01 *= dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
-            v23 *= dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
-          } else if constexpr (HAS_OPT) {
-            const u32x2_t r2 = opnd[i & 1][j];
-            v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
-            v23 += (f32x2_t){bf_lo(r2[1]), bf_hi(r2[1])};
-          }
-          o[0] = pack_bf2(v01[0], v01[1]);
-          o[1] = pack_bf2(v23[0], v23[1]);
+        } else if constexpr (EPI == EPI_DGELU) {
+          const u32x2_t u = opnd[i & 1][j];   // saved gelu'(u)
+          v01 *= (f32x2_t){bf_lo(u[0]), bf_hi(u[0])};
+          v23 *= (f32x2_t){bf_lo(u[1]), bf_hi(u[1])};
+        } else if constexpr (HAS_OPT) {
+          const u32x2_t r2 = opnd[i & 1][j];
+          v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
+          v23 += (f32x2_t){bf_lo(r2[1]), bf_hi(r2[1])};
         }
-        *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = o;
+        o[0] = pack_bf2(v01[0], v01[1]);
+        o[1] = pack_bf2(v23[0], v23[1]);
+        *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = o;
       }
     }
-    if constexpr (TWO_OUT) {
-      flush(p.aux_out, p.ldaux, ps * IPP * 16);
-#pragma unroll
-      for (int ii = 0; ii < IPP; ii++)
-#pragma unroll
-        for (int j = 0; j < FN; j++) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = second[ii][j];
-    }
-    flush((bf16_t*)p.C, p.ldc, ps * IPP * 16);
+    if constexpr (TWO_OUT) flush(p.aux_out, p.ldaux, ps * RPP * 16, 0);
+    flush((bf16_t*)p.C, p.ldc, ps * RPP * 16, TWO_OUT ? RPP : 0);
   }
 }
 

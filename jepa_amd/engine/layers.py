@@ -97,6 +97,7 @@ def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
         lses.append(lse)
     x1 = ops.gemm_nt(o, bw.proj.w, bias=bw.proj.b, residual=x)
     y2, mean2, rstd2 = ops.layernorm_fwd(x1, bw.norm2.g, bw.norm2.b, LN_EPS, save_stats=save)
+    # u: the fc1 epilogue saves gelu'(pre-activation) here (not the pre-activation): all the backward needs from it
     u = torch.empty((x.shape[0], bw.fc1.w.shape[0]), dtype=torch.bfloat16, device=x.device) if save else None
     g = ops.gemm_nt(y2, bw.fc1.w, bias=bw.fc1.b, aux_out=u, epilogue=ops.EPI_GELU)
     x2 = ops.gemm_nt(g, bw.fc2.w, bias=bw.fc2.b, residual=x1)

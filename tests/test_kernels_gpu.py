@@ -175,16 +175,19 @@ def test_gemm_gelu_epilogues(ops, M, N, K):
     A = bf(torch.randn(M, K, generator=g)).to(DEV)
     W = bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)
     bias = torch.randn(N, generator=g).to(DEV)
-    u_ref = A.float() @ W.float().t() + bias
-    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    gout = ops.gemm_nt(A, W, bias=bias, aux_out=u, epilogue=ops.EPI_GELU)
-    assert rel_l2(u, u_ref) < 4e-3
-    g_ref = torch.nn.functional.gelu(u.float())  # exact erf GELU of the stored pre-activation
+    u_ref = (A.float() @ W.float().t() + bias).to(torch.bfloat16).float()   # the epilogue rounds the pre-activation to bf16
+    dg = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    gout = ops.gemm_nt(A, W, bias=bias, aux_out=dg, epilogue=ops.EPI_GELU)
+    g_ref = torch.nn.functional.gelu(u_ref)  # exact erf GELU of the bf16 pre-activation
     assert rel_l2(gout, g_ref) < 4e-3, rel_l2(gout, g_ref)
-    # dgelu epilogue: out = (A W^T) * gelu'(u)
-    d = ops.gemm_nt(A, W, aux_in=u, epilogue=ops.EPI_DGELU)
-    uu = u.float().requires_grad_(True)
+    assert torch.equal(gout, ops.gemm_nt(A, W, bias=bias, epilogue=ops.EPI_GELU))   # saving the derivative changes nothing
+    # aux_out = gelu'(u) (bf16): the derivative is saved instead of the pre-activation
+    uu = u_ref.clone().requires_grad_(True)
     torch.nn.functional.gelu(uu).sum().backward()
+    assert rel_l2(dg, uu.grad) < 4e-3, rel_l2(dg, uu.grad)
+    assert (dg.float() - uu.grad).abs().max() < 2e-2   # half a bf16 ulp at 1.13 plus a one-ulp rounding flip of u itself
+    # dgelu epilogue: out = (A W^T) * saved derivative
+    d = ops.gemm_nt(A, W, aux_in=dg, epilogue=ops.EPI_DGELU)
     d_ref = (A.float() @ W.float().t()) * uu.grad
     assert rel_l2(d, d_ref) < 5e-3, rel_l2(d, d_ref)
 

@@ -119,8 +119,7 @@ def test_persistent_gemm_is_bit_identical_to_the_one_tile_kernel(M, N, K):
         if epi == 1:
             y = torch.nn.functional.gelu(y.to(torch.bfloat16).float())
         if epi == 2:
-            u = aux_in.float()
-            y = y * (0.5 * (1 + torch.erf(u / 2 ** 0.5)) + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5)
+            y = y * aux_in.float()   # the saved GELU derivative
         if res is not None:
             y = y + res.float()
         assert rel_l2(got.float().cpu(), y.cpu()) < 4e-3, (epi, rel_l2(got.float().cpu(), y.cpu()))
