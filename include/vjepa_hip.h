@@ -141,6 +141,21 @@ int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H);
 int vj_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B,
                 int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, vj_stream_t stream);
 
+/* ---- cross-attention of a few learned queries against frozen-encoder tokens (attentive probe, row f4 widened) ------
+ * CrossAttention.forward (src/models/utils/modules.py:140-157) as used by CrossAttentionBlock (modules.py:177-181) inside
+ * AttentivePooler / AttentiveClassifier (src/models/attentive_pooler.py:96-136; num_queries = 1 there).
+ * q: [B or 1, NQ, H*hd] bf16 (q_bstride = elements between samples, 0 when every sample shares the projected query);
+ * kv: packed kv-Linear output [B,N,2,H,hd] (modules.py:145 before the permute); resid (nullable): [NQ, H*hd] bf16 added to
+ * the result (the block's q + xattn(...)); out: [B,NQ,H*hd] bf16; lse2: [B,H,NQ] fp32 (nullable in inference).
+ * Matrix-vector work, HBM-bound: 4*N*hd bytes per (sample, head, query) forward, 12*N*hd backward.  The reference's
+ * `proj` Linear of CrossAttention is never applied (modules.py:156-157) and is not applied here. */
+int vj_xattn_fwd(const void* q, int64_t q_bstride, const void* kv, const void* resid, void* out, float* lse2, int64_t B,
+                 int64_t NQ, int64_t N, int64_t H, int64_t hd, float scale, vj_stream_t stream);
+/* dq [B,H*hd] bf16 (per sample; the caller sums over the batch when the query is shared), dkv [B,N,2,H,hd] bf16
+ * <- (dy [B,1,H*hd] bf16, saved q, kv, lse2).  NQ must be 1. */
+int vj_xattn_bwd(const void* q, int64_t q_bstride, const void* kv, const void* dy, const float* lse2, void* dq, void* dkv,
+                 int64_t B, int64_t NQ, int64_t N, int64_t H, int64_t hd, float scale, vj_stream_t stream);
+
 /* ---- predictor token assembly (predictor.py:194-221) --------------------------------------------------------
  * out[b, j<Ke] = embed[b,j] + pos[idx_e[b,j]];  out[b, Ke+j] = mask_token + pos[idx_p[b,j]] */
 int vj_pred_assemble_fwd(const void* e_bf16, const float* mask_token, const float* pos, const int64_t* idx_e,

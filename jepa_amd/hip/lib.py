@@ -70,6 +70,8 @@ SIGNATURES = {
     "vj_attn_set_variant": (I32, [I32]),
     "vj_attn_bwd_ws_bytes": (I64, [I64, I64, I64]),
     "vj_attn_bwd": (I32, [P, P, P, P, P, I64, I64, I64, I64, F32, P, I64, P]),
+    "vj_xattn_fwd": (I32, [P, I64, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
+    "vj_xattn_bwd": (I32, [P, I64, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
     "vj_pred_assemble_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, P]),
     "vj_target_rows": (I32, [P, P, P, P, P, I64, I64, I64, I64, F32, F32, P]),
     "vj_latent_loss_ws_bytes": (I64, []),

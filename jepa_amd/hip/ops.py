@@ -336,6 +336,29 @@ def attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
 
 
 # ---------------------------------------------------------------- predictor / loss
+def xattn_fwd(q, kv, B, NQ, N, H, hd, scale, resid=None, shared_q=True, save_lse=True, stream=None):
+    """Few-query cross-attention (vj_xattn_fwd): q [NQ, D] (shared_q) or [B, NQ, D], kv [B*N, 2*D] packed -> out [B*NQ, D] bf16,
+    lse2 [B, H, NQ] fp32 (None when not saved)."""
+    D = H * hd
+    _req(q, torch.bfloat16, "q"); _req(kv, torch.bfloat16, "kv")
+    out = torch.empty((B * NQ, D), dtype=torch.bfloat16, device=kv.device)
+    lse = torch.empty((B, H, NQ), dtype=torch.float32, device=kv.device) if save_lse else None
+    check(load_library().vj_xattn_fwd(_ptr(q), 0 if shared_q else NQ * D, _ptr(kv), _ptr(resid), _ptr(out), _ptr(lse), B, NQ, N, H,
+                                      hd, float(scale), _stream(stream)), "vj_xattn_fwd")
+    return out, lse
+
+
+def xattn_bwd(q, kv, dy, lse, B, N, H, hd, scale, shared_q=True, stream=None):
+    """Backward of xattn_fwd for one query per sample: returns dq [B, D] bf16 (per sample) and dkv [B*N, 2*D] bf16."""
+    D = H * hd
+    _req(q, torch.bfloat16, "q"); _req(kv, torch.bfloat16, "kv"); _req(dy, torch.bfloat16, "dy")
+    dq = torch.empty((B, D), dtype=torch.bfloat16, device=kv.device)
+    dkv = torch.empty_like(kv)
+    check(load_library().vj_xattn_bwd(_ptr(q), 0 if shared_q else D, _ptr(kv), _ptr(dy), _ptr(lse), _ptr(dq), _ptr(dkv), B, 1, N, H,
+                                      hd, float(scale), _stream(stream)), "vj_xattn_bwd")
+    return dq, dkv
+
+
 def pred_assemble(e, mask_token, pos, idx_e, idx_p, out=None, stream=None):
     lib = load_library()
     _req(e, BF16, "e")
