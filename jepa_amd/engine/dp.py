@@ -94,6 +94,7 @@ class GradReducer:
             return
         self.launched = []
         self._pending = []
+        self._ev_next = 0           # ordering events are pooled: one per bucket position, re-recorded every step
         self._producer = producer_stream
         if self.arena.G.is_cuda and self.overlap and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=self.arena.G.device)
@@ -102,7 +103,14 @@ class GradReducer:
         g = self.arena.G[lo:hi]
         self.launched.append((lo, hi))
         if g.is_cuda and self.overlap:
-            ev = torch.cuda.Event()
+            # (a stream's wait on an event binds to the record that precedes the wait call, so re-recording the same event
+            #  object in the next step cannot disturb a wait that is already enqueued)
+            pool = self.__dict__.setdefault("_ev_pool", [])
+            nxt = self.__dict__.get("_ev_next", 0)
+            if nxt >= len(pool):
+                pool.append(torch.cuda.Event())
+            ev = pool[nxt]
+            self._ev_next = nxt + 1
             ev.record(producer if producer is not None else torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             if self._capi is not None:
