@@ -199,6 +199,9 @@ class AttentivePooler(nn.Module):
         """x: [B, N, D] frozen-encoder tokens (any float dtype, GPU) -> [B, 1, D] fp32."""
         if not x.is_cuda:
             raise ValueError("AttentivePooler: jepa_amd computes only on the GPU through libvjepa_hip.so (no CPU fallback)")
+        if x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("AttentivePooler: the features come from a FROZEN encoder (eval.py:330-337 runs it under "
+                                      "torch.no_grad()); no gradient is propagated into them")
         blk = self.cross_attention_block
         eps = blk.norm1.eps
         return _PoolerFn.apply(x, blk.xattn.num_heads, eps, self.query_tokens, blk.norm1.weight, blk.norm1.bias, blk.xattn.q.weight,

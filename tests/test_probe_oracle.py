@@ -31,3 +31,24 @@ def test_probe_oracle_matches_reference_fixture(name):
     assert "pooler.cross_attention_block.xattn.proj.weight" in w and "pooler.cross_attention_block.xattn.proj.weight" not in g
     for k in g:
         assert torch.allclose(o_grads[k], g[k], rtol=1e-4, atol=1e-7), (k, (o_grads[k] - g[k]).abs().max())
+
+
+def test_probe_module_keeps_the_reference_names_and_has_no_cpu_path():
+    """Drop-in check without a GPU: the HIP-backed AttentiveClassifier exposes exactly the reference's parameter names and shapes
+    (the fixture's state dict loads strictly), re-initialises like the reference (LayerNorm (1, 0), zero biases, proj / fc2 rescaled
+    by 1/sqrt(2)), refuses unsupported constructor settings and raises on CPU tensors instead of falling back."""
+    from jepa_amd.src.models.attentive_pooler import AttentiveClassifier, AttentivePooler
+    (B, N, D, H, C), w, g, x, labels, logits, loss = load_case("a")
+    m = AttentiveClassifier(embed_dim=D, num_heads=H, depth=1, num_classes=C)
+    assert {n: tuple(p.shape) for n, p in m.named_parameters()} == {k: tuple(v.shape) for k, v in w.items()}
+    blk = m.pooler.cross_attention_block
+    assert float(blk.norm1.weight.min()) == 1.0 and float(blk.norm1.bias.abs().max()) == 0.0
+    assert float(blk.xattn.kv.bias.abs().max()) == 0.0   # (the head `linear` keeps nn.Linear's default init, as in the reference)
+    # trunc_normal(std=0.02) then / sqrt(2) for fc2 and the (never applied) proj: |w| <= 0.04 / sqrt(2)
+    assert float(blk.mlp.fc2.weight.abs().max()) <= 0.04 / 2 ** 0.5 + 1e-7 < float(blk.mlp.fc1.weight.abs().max()) + 0.02
+    m.load_state_dict(w, strict=True)
+    with pytest.raises(ValueError):
+        m(x)
+    for kw in (dict(num_queries=2), dict(depth=2), dict(complete_block=False)):
+        with pytest.raises(NotImplementedError):
+            AttentivePooler(embed_dim=D, num_heads=H, **kw)
