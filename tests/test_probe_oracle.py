@@ -44,8 +44,10 @@ def test_probe_module_keeps_the_reference_names_and_has_no_cpu_path():
     blk = m.pooler.cross_attention_block
     assert float(blk.norm1.weight.min()) == 1.0 and float(blk.norm1.bias.abs().max()) == 0.0
     assert float(blk.xattn.kv.bias.abs().max()) == 0.0   # (the head `linear` keeps nn.Linear's default init, as in the reference)
-    # trunc_normal(std=0.02) then / sqrt(2) for fc2 and the (never applied) proj: |w| <= 0.04 / sqrt(2)
-    assert float(blk.mlp.fc2.weight.abs().max()) <= 0.04 / 2 ** 0.5 + 1e-7 < float(blk.mlp.fc1.weight.abs().max()) + 0.02
+    # trunc_normal(std=0.02), then / sqrt(2) for fc2 and the (never applied) proj (attentive_pooler.py:68-81)
+    assert abs(float(blk.mlp.fc1.weight.std()) - 0.02) < 0.002 and abs(float(blk.xattn.kv.weight.std()) - 0.02) < 0.002
+    assert abs(float(blk.mlp.fc2.weight.std()) - 0.02 / 2 ** 0.5) < 0.0015
+    assert abs(float(blk.xattn.proj.weight.std()) - 0.02 / 2 ** 0.5) < 0.0015
     m.load_state_dict(w, strict=True)
     with pytest.raises(ValueError):
         m(x)
