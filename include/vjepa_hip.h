@@ -295,7 +295,7 @@ int vj_comm_destroy(vj_comm_t comm);
 /* ---- run-time tuning switches ------------------------------------------------------------------------------
  * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
  * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_tn",
- * "wgrad_group", "wgrad_slow_issue", "gemm_dbg".  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * "wgrad_group", "wgrad_slow_issue", "attn_dkdv_kt", "gemm_dbg".  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
  * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
 int vj_set_option(const char* name, int value);
 int vj_get_option(const char* name, int* value);

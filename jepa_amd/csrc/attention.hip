@@ -19,6 +19,7 @@
 // Softmax is computed in base 2: s2 = (q.k) * scale * log2(e); lse2 = max2 + log2(sum) is what the forward
 // saves for the backward (an internal format, produced and consumed only here).
 #include "common.hpp"
+#include "options.hpp"
 #include <type_traits>
 #include <cstdlib>
 
@@ -439,11 +440,16 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
 }
 
 // =============================================================================================================
-// backward, part 1: dK, dV.  One workgroup per 64-key block (16 keys per wave), loop over 64-query tiles.
+// backward, part 1: dK, dV.  One workgroup per 64*KT-key block (16*KT keys per wave), loop over 64-query tiles.
 //   S = Q K^T (lane: S[q = qt*16+4g+r][key = li]),  P = exp2(S*sc - lse2[q]),  dP = dO V^T,
 //   dS = P (dP - delta[q]),  dV^T += dO^T P,  dK^T += Q^T dS  (then * scale)
+// KT = 16-key tiles per wave.  Every LDS read instruction (ds_read_b128 and the half-as-wide ds_read_b64_tr_b16 alike)
+// occupies the CU's LDS pipe for 4 cycles, i.e. costs a SIMD 16 cycles of its share -- as much as one MFMA
+// (tools/probes/valu_probe.hip).  With KT = 1 a wave issues 32 (hd <= 32) ... 56 (hd = 64) of them per 64-query tile for
+// 16 MFMAs + the soft-max arithmetic of 16 scores per lane: the kernel is bound by LDS INSTRUCTIONS.  The Q / dO fragments
+// and their transposed reads do not depend on the key, so KT = 2 reuses every one of them for two key tiles.
 // =============================================================================================================
-template <int HDP>
+template <int HDP, int KT>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv,
                                                             const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse2,
@@ -470,22 +476,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
   const bf16_t* dobase = dout + (int64_t)b * S * os + (int64_t)h * hd;
   const float* lse_b = lse2 + ((int64_t)b * H + h) * S;
   const float* dl_b = delta + ((int64_t)b * H + h) * S;
-  const int key = kb * 64 + w * 16 + li;
-  const bool key_ok = key < S;
+  int key[KT];
+  bool key_ok[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; kt++) {
+    key[kt] = kb * (64 * KT) + (w * KT + kt) * 16 + li;
+    key_ok[kt] = key[kt] < S;
+  }
 
-  bf16x8_t kf[KS], vf[KS];
+  bf16x8_t kf[KT][KS], vf[KT][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ks++) {
-    const int d0 = ks * 32 + 8 * g;
-    kf[ks] = load_frag_global(kbase + (int64_t)key * rs + d0, key_ok && d0 < hd);
-    vf[ks] = load_frag_global(vbase + (int64_t)key * rs + d0, key_ok && d0 < hd);
-  }
-  f32x4_t dvacc[DT], dkacc[DT];
+  for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-  for (int dt = 0; dt < DT; dt++) {
-    dvacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    dkacc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  }
+    for (int ks = 0; ks < KS; ks++) {
+      const int d0 = ks * 32 + 8 * g;
+      kf[kt][ks] = load_frag_global(kbase + (int64_t)key[kt] * rs + d0, key_ok[kt] && d0 < hd);
+      vf[kt][ks] = load_frag_global(vbase + (int64_t)key[kt] * rs + d0, key_ok[kt] && d0 < hd);
+    }
+  f32x4_t dvacc[KT][DT], dkacc[KT][DT];
+#pragma unroll
+  for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) {
+      dvacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      dkacc[kt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
 
   float lse_r = 0.f, dl_r = 0.f;
   const f32x2_t sc2 = {sc, sc};
@@ -526,71 +541,90 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
       else dma.template issue<false>(qbase, rs, dobase, os, (t + 1) * 64, S, smem + ((t + 1) & 1) * BUFB);
     }
 
-    float pv[4][4], dsv[4][4];
+    float pv[KT][4][4], dsv[KT][4][4];
 #pragma unroll
     for (int qt = 0; qt < 4; qt++) {
       const float4 lse4 = *(const float4*)(lse_s + qt * 16 + 4 * g);   // queries qt*16 + 4g + {0..3}
       const float4 ndl4 = *(const float4*)(dl_s + qt * 16 + 4 * g);    // -delta of the same queries
-      // the dP accumulator STARTS at -delta[q] (this lane's four rows): dP - delta comes out of the matrix pipe, the
-      // kernel is bound by vector issue
-      f32x4_t sacc = {0.f, 0.f, 0.f, 0.f}, dpacc = {ndl4.x, ndl4.y, ndl4.z, ndl4.w};
+      // the dP accumulator STARTS at -delta[q] (this lane's four rows): dP - delta comes out of the matrix pipe
+      f32x4_t sacc[KT], dpacc[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; kt++) {
+        sacc[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        dpacc[kt] = (f32x4_t){ndl4.x, ndl4.y, ndl4.z, ndl4.w};
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) {
-        const bf16x8_t qa = RowTile<HDP>::frag(q_lds, qt * 16 + li, ks * 4 + g);
+        const bf16x8_t qa = RowTile<HDP>::frag(q_lds, qt * 16 + li, ks * 4 + g);     // read ONCE for all KT key tiles
         const bf16x8_t da = RowTile<HDP>::frag(do_lds, qt * 16 + li, ks * 4 + g);
-        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc, 0, 0, 0);
-        dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], dpacc, 0, 0, 0);
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+          sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], sacc[kt], 0, 0, 0);
+          dpacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dpacc[kt], 0, 0, 0);
+        }
       }
       const f32x2_t nl[2] = {{-lse4.x, -lse4.y}, {-lse4.z, -lse4.w}};
 #pragma unroll
-      for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
-        const f32x2_t sv = {sacc[2 * hf], sacc[2 * hf + 1]}, dpv = {dpacc[2 * hf], dpacc[2 * hf + 1]};
-        const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl[hf]);   // padded queries: lse = +inf -> P = 0
-        const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-        const f32x2_t ds = e * dpv;
-        pv[qt][2 * hf] = e[0];
-        pv[qt][2 * hf + 1] = e[1];
-        dsv[qt][2 * hf] = ds[0];
-        dsv[qt][2 * hf + 1] = ds[1];
-      }
+      for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
+          const f32x2_t sv = {sacc[kt][2 * hf], sacc[kt][2 * hf + 1]}, dpv = {dpacc[kt][2 * hf], dpacc[kt][2 * hf + 1]};
+          const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl[hf]);   // padded queries: lse = +inf -> P = 0
+          const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          const f32x2_t ds = e * dpv;
+          pv[kt][qt][2 * hf] = e[0];
+          pv[kt][qt][2 * hf + 1] = e[1];
+          dsv[kt][qt][2 * hf] = ds[0];
+          dsv[kt][qt][2 * hf + 1] = ds[1];
+        }
     }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      u32x4_t pw, dw;
-      pw[0] = cvt_pk_bf16(pv[2 * c][0], pv[2 * c][1]);
-      pw[1] = cvt_pk_bf16(pv[2 * c][2], pv[2 * c][3]);
-      pw[2] = cvt_pk_bf16(pv[2 * c + 1][0], pv[2 * c + 1][1]);
-      pw[3] = cvt_pk_bf16(pv[2 * c + 1][2], pv[2 * c + 1][3]);
-      dw[0] = cvt_pk_bf16(dsv[2 * c][0], dsv[2 * c][1]);
-      dw[1] = cvt_pk_bf16(dsv[2 * c][2], dsv[2 * c][3]);
-      dw[2] = cvt_pk_bf16(dsv[2 * c + 1][0], dsv[2 * c + 1][1]);
-      dw[3] = cvt_pk_bf16(dsv[2 * c + 1][2], dsv[2 * c + 1][3]);
-      const bf16x8_t pfr = __builtin_bit_cast(bf16x8_t, pw);
-      const bf16x8_t dfr = __builtin_bit_cast(bf16x8_t, dw);
+      bf16x8_t pfr[KT], dfr[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; kt++) {
+        u32x4_t pw, dw;
+        pw[0] = cvt_pk_bf16(pv[kt][2 * c][0], pv[kt][2 * c][1]);
+        pw[1] = cvt_pk_bf16(pv[kt][2 * c][2], pv[kt][2 * c][3]);
+        pw[2] = cvt_pk_bf16(pv[kt][2 * c + 1][0], pv[kt][2 * c + 1][1]);
+        pw[3] = cvt_pk_bf16(pv[kt][2 * c + 1][2], pv[kt][2 * c + 1][3]);
+        dw[0] = cvt_pk_bf16(dsv[kt][2 * c][0], dsv[kt][2 * c][1]);
+        dw[1] = cvt_pk_bf16(dsv[kt][2 * c][2], dsv[kt][2 * c][3]);
+        dw[2] = cvt_pk_bf16(dsv[kt][2 * c + 1][0], dsv[kt][2 * c + 1][1]);
+        dw[3] = cvt_pk_bf16(dsv[kt][2 * c + 1][2], dsv[kt][2 * c + 1][3]);
+        pfr[kt] = __builtin_bit_cast(bf16x8_t, pw);
+        dfr[kt] = __builtin_bit_cast(bf16x8_t, dw);
+      }
 #pragma unroll
       for (int dt = 0; dt < DT; dt++) {
-        const bf16x8_t dot_f = trf.load(do_lds, c * 32, dt * 16);
+        const bf16x8_t dot_f = trf.load(do_lds, c * 32, dt * 16);                     // read ONCE for all KT key tiles
         const bf16x8_t qt_f = trf.load(q_lds, c * 32, dt * 16);
-        dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr, dvacc[dt], 0, 0, 0);
-        dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dfr, dkacc[dt], 0, 0, 0);
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+          dvacc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pfr[kt], dvacc[kt][dt], 0, 0, 0);
+          dkacc[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dfr[kt], dkacc[kt][dt], 0, 0, 0);
+        }
       }
     }
   }
 
-  if (key_ok) {
-    bf16_t* dkp = dqkv + ((int64_t)b * S + key) * rs + (int64_t)H * hd + (int64_t)h * hd;
-    bf16_t* dvp = dkp + (int64_t)H * hd;
 #pragma unroll
-    for (int dt = 0; dt < DT; dt++) {
-      const int d = dt * 16 + 4 * g;
-      if (d < hd) {
-        u32x2_t a, c;
-        a[0] = cvt_pk_bf16(dkacc[dt][0] * scale, dkacc[dt][1] * scale);
-        a[1] = cvt_pk_bf16(dkacc[dt][2] * scale, dkacc[dt][3] * scale);
-        c[0] = cvt_pk_bf16(dvacc[dt][0], dvacc[dt][1]);
-        c[1] = cvt_pk_bf16(dvacc[dt][2], dvacc[dt][3]);
-        *(u32x2_t*)(dkp + d) = a;
-        *(u32x2_t*)(dvp + d) = c;
+  for (int kt = 0; kt < KT; kt++) {
+    if (key_ok[kt]) {
+      bf16_t* dkp = dqkv + ((int64_t)b * S + key[kt]) * rs + (int64_t)H * hd + (int64_t)h * hd;
+      bf16_t* dvp = dkp + (int64_t)H * hd;
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const int d = dt * 16 + 4 * g;
+        if (d < hd) {
+          u32x2_t a, c;
+          a[0] = cvt_pk_bf16(dkacc[kt][dt][0] * scale, dkacc[kt][dt][1] * scale);
+          a[1] = cvt_pk_bf16(dkacc[kt][dt][2] * scale, dkacc[kt][dt][3] * scale);
+          c[0] = cvt_pk_bf16(dvacc[kt][dt][0], dvacc[kt][dt][1]);
+          c[1] = cvt_pk_bf16(dvacc[kt][dt][2], dvacc[kt][dt][3]);
+          *(u32x2_t*)(dkp + d) = a;
+          *(u32x2_t*)(dvp + d) = c;
+        }
       }
     }
   }
@@ -835,23 +869,28 @@ extern "C" int vj_attn_bwd(const void* qkv, const void* o, const void* dout, con
   VJ_CHECK_ARG(ws_bytes >= vj_attn_bwd_ws_bytes(B, S, H), "vj_attn_bwd: workspace too small");
   if (B * S == 0) return 0;
   float* delta = (float*)ws;
-  const int nkb = (int)cdiv64(S, 64), nqb = (int)cdiv64(S, 128);
-  const int64_t g1 = B * H * nkb, g2 = B * H * nqb;
-  VJ_CHECK_ARG(g1 < (1ll << 31), "vj_attn_bwd: grid too large");
+  const int nqb = (int)cdiv64(S, 128);
+  const int64_t g2 = B * H * nqb;
+  VJ_CHECK_ARG(B * H * cdiv64(S, 64) < (1ll << 31), "vj_attn_bwd: grid too large");
   const float sc = scale * LOG2E;
-  // dQ first: it also produces delta[b,h,s] = dO . O for the dK/dV kernel behind it on the same stream
-#define VJ_BWD_LAUNCH(HDPV)                                                                                        \
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<HDPV>, dim3((unsigned)g2), dim3(256), 0, stream, (const bf16_t*)qkv,       \
-                     (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H,     \
-                     (int)hd, sc, scale, nqb);                                                                     \
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HDPV>, dim3((unsigned)g1), dim3(256), 0, stream, (const bf16_t*)qkv,     \
-                     (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H, (int)hd, sc, scale,   \
-                     nkb);
+  // dQ first: it also produces delta[b,h,s] = dO . O for the dK/dV kernel behind it on the same stream.
+  // dK/dV: KTV 16-key tiles per wave (option attn_dkdv_kt: 0 = per head-dim class, 1 / 2 forced)
+#define VJ_BWD_LAUNCH(HDPV, KTV)                                                                                   \
+  do {                                                                                                             \
+    const int nkb = (int)cdiv64(S, 64 * KTV);                                                                      \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HDPV>, dim3((unsigned)g2), dim3(256), 0, stream, (const bf16_t*)qkv,     \
+                       (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H,   \
+                       (int)hd, sc, scale, nqb);                                                                   \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV>), dim3((unsigned)(B * H * nkb)), dim3(256), 0, stream,      \
+                       (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H, \
+                       (int)hd, sc, scale, nkb);                                                                   \
+  } while (0)
+  const int kt_opt = vj_opt(VJ_OPT_ATTN_DKDV_KT);
   switch (pick_hdp(hd)) {
-    case 32: VJ_BWD_LAUNCH(32); break;
-    case 64: VJ_BWD_LAUNCH(64); break;
-    case 96: VJ_BWD_LAUNCH(96); break;
-    default: VJ_BWD_LAUNCH(128);
+    case 32: if (kt_opt == 1) VJ_BWD_LAUNCH(32, 1); else VJ_BWD_LAUNCH(32, 2); break;
+    case 64: if (kt_opt == 2) VJ_BWD_LAUNCH(64, 2); else VJ_BWD_LAUNCH(64, 1); break;
+    case 96: VJ_BWD_LAUNCH(96, 1); break;
+    default: VJ_BWD_LAUNCH(128, 1);
   }
 #undef VJ_BWD_LAUNCH
   VJ_LAUNCH_CHECK("vj_attn_bwd");

@@ -14,7 +14,8 @@ struct OptDef {
 };
 const OptDef kDefs[VJ_OPT_COUNT] = {
     {"gemm_fwd_flags", 0}, {"gemm_dgrad_flags", 0}, {"gemm_4w", 0},         {"gemm_persist", 1},
-    {"wgrad_tn", 1},       {"wgrad_group", 1},      {"wgrad_slow_issue", 0}, {"gemm_dbg", 0},
+    {"wgrad_tn", 1},       {"wgrad_group", 1},      {"wgrad_slow_issue", 0}, {"attn_dkdv_kt", 0},
+    {"gemm_dbg", 0},
 };
 std::atomic<int> g_val[VJ_OPT_COUNT];
 std::once_flag g_once;

@@ -18,6 +18,7 @@ enum VjOpt {
   VJ_OPT_WGRAD_GROUP,          // 1 (default): the four weight gradients of a block in ONE launch (vj_gemm_bf16_tn_grouped);
                                // 0: one launch each (different fp32 summation order: results agree to rounding, not bitwise)
   VJ_OPT_WGRAD_SLOW_ISSUE,     // 1: the TN kernel's K loop issues its parts through the generic address path (A/B only)
+  VJ_OPT_ATTN_DKDV_KT,         // 16-key tiles per wave in the attention dK/dV kernel: 0 (default) per head-dim class, 1 / 2 forced
   VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)
   VJ_OPT_COUNT
 };

@@ -272,6 +272,29 @@ def test_attention_fwd_bwd(ops, B, S, H, hd):
         assert e < 1.5e-2, (name, e)
 
 
+@pytest.mark.parametrize("B,S,H,hd", ATTN_SHAPES)
+def test_attention_dkdv_two_key_tiles_per_wave_is_bit_identical(ops, B, S, H, hd):
+    """attn_bwd_dkdv_kernel<HDP, 2> (32 keys per wave: every Q / dO fragment and transposed read serves two key tiles) accumulates each
+    dK / dV element over the query tiles in the same order as the 16-keys-per-wave form: dqkv must be equal bit for bit.  Only the
+    head-dim classes that instantiate both forms (hd <= 64) are compared."""
+    if hd > 64:
+        pytest.skip("one form only for this head-dim class")
+    from jepa_amd.hip.lib import set_option
+    g = torch.Generator().manual_seed(21)
+    qkv = bf(torch.randn(B * S, 3 * H * hd, generator=g)).to(DEV)
+    dout = bf(torch.randn(B * S, H * hd, generator=g)).to(DEV)
+    o, lse = ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5)
+    old = set_option("attn_dkdv_kt", 1)
+    try:
+        d1 = ops.attn_bwd(qkv, o, dout, lse, B, S, H, hd, hd ** -0.5).clone()
+        set_option("attn_dkdv_kt", 2)
+        d2 = ops.attn_bwd(qkv, o, dout, lse, B, S, H, hd, hd ** -0.5).clone()
+        torch.cuda.synchronize()
+    finally:
+        set_option("attn_dkdv_kt", old)
+    assert torch.equal(d1, d2), int((d1 != d2).sum())
+
+
 def test_attention_forced_rescale(ops):
     """One key row spiked against one query row at a late tile: the online-softmax rescale path must be exact."""
     B, S, H, hd = 1, 300, 1, 64

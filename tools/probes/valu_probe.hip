@@ -39,6 +39,13 @@ __global__ void probe(long long* out, float* sink) {
     r[i] = 0.001f * (threadIdx.x + i);
     p[i] = (f2){r[i], r[i] + 1.f};
   }
+  __shared__ __attribute__((aligned(16))) char lbuf[16384];
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  u4 lq[8];
+  u2 lt[8];
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) ((unsigned*)lbuf)[i] = i;
+  const unsigned laddr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbuf + (threadIdx.x & 63) * 16;
   f32x4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   bf16x8_t x, y;
   for (int i = 0; i < 8; i++) { x[i] = (__bf16)(0.01f * i); y[i] = (__bf16)(0.02f * i); }
@@ -108,6 +115,21 @@ __global__ void probe(long long* out, float* sink) {
     if constexpr (KIND == 24) { for (int k = 0; k < 4; k++) { MF(0) OP_MAX3(0) OP_MAX3(1) MF(1) OP_MAX3(2) OP_MAX3(3) MF(2) OP_MAX3(4) OP_MAX3(5) MF(3) OP_MAX3(6) OP_MAX3(7) } }
     if constexpr (KIND == 25) { for (int k = 0; k < 4; k++) { MF(0) OP_EXP(0) OP_EXP(1) MF(1) OP_EXP(2) OP_EXP(3) MF(2) OP_EXP(4) OP_EXP(5) MF(3) OP_EXP(6) OP_EXP(7) } }
     if constexpr (KIND == 26) { for (int k = 0; k < 4; k++) { MF(0) OP_PKFMA(0) OP_PKFMA(1) OP_PKFMA(2) OP_PKFMA(3) MF(1) OP_PKFMA(4) OP_PKFMA(5) OP_PKFMA(6) OP_PKFMA(7) MF(2) OP_PKFMA(0) OP_PKFMA(1) OP_PKFMA(2) OP_PKFMA(3) MF(3) OP_PKFMA(4) OP_PKFMA(5) OP_PKFMA(6) OP_PKFMA(7) } }
+    // LDS reads: issue cost alone and next to MFMAs (results land in scratch registers, one lgkmcnt(0) per group)
+#define OP_LDS(i)  asm volatile("ds_read_b128 %0, %1 offset:" #i "*1024" : "=v"(lq[i]) : "v"(laddr));
+#define OP_LDST(i) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #i "*1024" : "=v"(lt[i]) : "v"(laddr));
+    if constexpr (KIND == 30) { BODY8(OP_LDS) BODY8(OP_LDS) asm volatile("s_waitcnt lgkmcnt(0)"); }
+    if constexpr (KIND == 31) { BODY8(OP_LDST) BODY8(OP_LDST) asm volatile("s_waitcnt lgkmcnt(0)"); }
+    if constexpr (KIND == 32) { for (int k = 0; k < 4; k++) { MF(0) OP_LDS(0) MF(1) OP_LDS(1) MF(2) OP_LDS(2) MF(3) OP_LDS(3) } asm volatile("s_waitcnt lgkmcnt(0)"); }
+    if constexpr (KIND == 33) { for (int k = 0; k < 4; k++) { MF(0) OP_LDS(0) OP_LDS(1) MF(1) OP_LDS(2) OP_LDS(3) MF(2) OP_LDS(4) OP_LDS(5) MF(3) OP_LDS(6) OP_LDS(7) } asm volatile("s_waitcnt lgkmcnt(0)"); }
+    if constexpr (KIND == 34) { for (int k = 0; k < 4; k++) { MF(0) OP_LDST(0) OP_LDST(1) MF(1) OP_LDST(2) OP_LDST(3) MF(2) OP_LDST(4) OP_LDST(5) MF(3) OP_LDST(6) OP_LDST(7) } asm volatile("s_waitcnt lgkmcnt(0)"); }
+    if constexpr (KIND == 35) {   // barrier cost: 16 MFMAs, one s_barrier
+      for (int k = 0; k < 4; k++) { MF(0) MF(1) MF(2) MF(3) }
+      __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (KIND == 36) {   // 16 MFMAs in 4 groups with a barrier after each
+      for (int k = 0; k < 4; k++) { MF(0) MF(1) MF(2) MF(3) __builtin_amdgcn_s_barrier(); }
+    }
     // the tile mix with every packed f32 instruction replaced by two plain ones
     if constexpr (KIND == 17) {
       for (int k = 0; k < 4; k++) { MF(0) MF(1) MF(2) MF(3) }
@@ -128,6 +150,7 @@ __global__ void probe(long long* out, float* sink) {
   float s = 0.f;
   for (int i = 0; i < 8; i++) s += r[i] + p[i][0] + p[i][1];
   for (int j = 0; j < 4; j++) s += acc[j][0];
+  for (int i = 0; i < 8; i++) s += (float)(lq[i][0] + lt[i][0]);
   if (s == 123.456f) sink[0] = s;
   if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
@@ -155,7 +178,7 @@ int main() {
   float* sink;
   hipMalloc(&dout, 4096);
   hipMalloc(&sink, 64);
-  for (int w = 2; w <= 4; w++) {
+  for (int w = 2; w <= 4; w += 2) {
     run<13>("16 x v_mov_b32", 16, w, dout, sink);
     run<0>("16 x v_fma_f32", 16, w, dout, sink);
     run<1>("16 x v_pk_fma_f32", 16, w, dout, sink);
@@ -177,6 +200,13 @@ int main() {
     run<25>("16 x (mfma + 2 v_exp_f32)   [alone 16+16.4]", 48, w, dout, sink);
     run<23>("16 x (mfma + 2 v_cvt_pk)    [alone 16+8.8]", 48, w, dout, sink);
     run<24>("16 x (mfma + 2 v_max3_f32)  [alone 16+8.6]", 48, w, dout, sink);
+    run<30>("16 x ds_read_b128 + wait", 16, w, dout, sink);
+    run<31>("16 x ds_read_b64_tr_b16 + wait", 16, w, dout, sink);
+    run<32>("16 x (mfma + 1 ds_read_b128)", 32, w, dout, sink);
+    run<33>("16 x (mfma + 2 ds_read_b128)", 48, w, dout, sink);
+    run<34>("16 x (mfma + 2 ds_read_b64_tr_b16)", 48, w, dout, sink);
+    run<35>("16 x mfma + 1 s_barrier", 17, w, dout, sink);
+    run<36>("4 x (4 mfma + s_barrier)", 20, w, dout, sink);
     run<18>("attention tile, plain instead of packed: vector part alone (160)", 160, w, dout, sink);
     run<17>("attention tile, plain instead of packed: 16 mfma | vector | 16 mfma", 192, w, dout, sink);
     run<16>("attention tile: vector part alone (120)", 120, w, dout, sink);
