@@ -1,0 +1,34 @@
+"""CPU (hipcc cross-compiles without a GPU): no gfx950 kernel of the library may spill vector registers.
+
+A spill is a performance cliff that nothing else in the suite would notice -- results stay correct.  It happened twice while the
+GEMM epilogues were being changed in round 3 (scratch loads landed inside the persistent kernel's tile loop, where the wait for them
+also drains the epilogue's stores); the register allocator of hipcc reacts chaotically to small source changes, so the guard is a test.
+Every csrc/*.hip is compiled device-only to assembly with the flags of jepa_amd/build.py and the kernel metadata is read back."""
+import concurrent.futures
+import os
+import re
+import subprocess
+
+from jepa_amd import build as vb
+
+
+def _asm(src):
+    base = os.path.basename(src)
+    cmd = [vb._hipcc()] + vb.CXXFLAGS + vb.EXTRA_FLAGS.get(base, []) + ["-x", "hip", "--cuda-device-only", "-S", src, "-o", "-"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return base, r.stdout
+
+
+def test_no_kernel_spills_vector_registers():
+    srcs = sorted(os.path.join(vb.CSRC, f) for f in os.listdir(vb.CSRC) if f.endswith(".hip"))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        outs = list(ex.map(_asm, srcs))
+    n_kernels, offenders = 0, []
+    for base, text in outs:
+        for name, spill in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+            n_kernels += 1
+            if int(spill) != 0:
+                offenders.append((base, name, int(spill)))
+    assert n_kernels >= 100, n_kernels          # 106 kernels at the end of round 3
+    assert not offenders, offenders
