@@ -92,7 +92,9 @@ def test_xattn_kernel_against_sdpa():
     dims 24 / 64 / 80 / 128, against F.scaled_dot_product_attention in fp32."""
     from jepa_amd.hip import ops
     g = torch.Generator().manual_seed(3)
-    for B, NQ, N, H, hd in [(2, 3, 77, 2, 64), (1, 1, 1, 1, 24), (3, 1, 1568, 16, 64), (2, 1, 300, 4, 80), (1, 2, 130, 2, 128)]:
+    # (the last case: eight 1568-token segments attended across (eval.py `attend_across_segments`), 109 KB of dynamic LDS in the backward)
+    for B, NQ, N, H, hd in [(2, 3, 77, 2, 64), (1, 1, 1, 1, 24), (3, 1, 1568, 16, 64), (2, 1, 300, 4, 80), (1, 2, 130, 2, 128),
+                            (1, 1, 12544, 2, 64)]:
         D = H * hd
         q = (torch.randn(B, NQ, D, generator=g)).to(torch.bfloat16).to(DEV)
         kv = (torch.randn(B * N, 2 * D, generator=g)).to(torch.bfloat16).to(DEV)
