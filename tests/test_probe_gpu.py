@@ -1,9 +1,6 @@
 """GPU: the trainable attentive probe (jepa_amd/src/models/attentive_pooler.py over csrc/xattn.hip and the GEMM / LayerNorm /
 weight-gradient kernels) against (i) the fixture generated from the real reference AttentiveClassifier and (ii) the fp32 oracle
 (oracle/probe_oracle.py, run by eager PyTorch as the checker) at the size the reference's evals use."""
-import os
-
-import numpy as np
 import pytest
 import torch
 
