@@ -2,17 +2,21 @@
 """V-JEPA pretraining-step benchmark on MI355X (BASELINE.json metric: clips/sec, fwd+bwd+EMA, ViT-L/16 16x224x224).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: re-executes itself under
+                                                           # torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # the same ranks started by an external launcher
 
 A "step" is one pass of the hot path (reference app/vjepa/train.py:414-487: schedules, target forward,
 context+predictor forward/backward, latent loss, gradient all-reduce, AdamW, EMA) over one batch of synthetic
 clips already resident in HBM, with mask indices drawn by the reference-compatible multiblock collator.
 Weak scaling: every rank processes its own B=24 clips.  Rank 0 prints ONE JSON line.
 
-`roofline` is read on the dominant kernel family (the bf16 MFMA GEMM): algorithmic 2*M*N*K of every launch
-divided by its duration measured with HIP events on the launch stream, in an instrumented pass of the same
-workload run right after the un-instrumented timed region (`value` never includes instrumentation).
+`roofline.achieved / frac` is the WHOLE STEP (the north-star quantity): matmul FLOPs of the step (engine/flops.py) over the
+timed region, against the dense bf16 MFMA peak.  Its sub-objects `gemm_family`, `dominant_kernel`, `attn_fwd`, `attn_bwd`
+come from an instrumented single-stream pass of the same workload run right after the un-instrumented timed region
+(HIP events per launch on the launch stream; `value` never includes instrumentation): algorithmic 2*M*N*K of every launch
+divided by its duration.  `traffic` = HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes.
 `cpu_baseline` times the pinned CPU oracle (a port of the reference arithmetic) on the host cores, rank 0, N=1.
 """
 import argparse
@@ -177,6 +181,97 @@ def cpu_baseline(wl_name):
                       f"{n_timed} timed steps, torch CPU kernels with {cores} threads"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves, one process per GPU,
+    by re-executing this file under torch.distributed.run (the reference's launcher spawns one process per device the same
+    way, app/main.py:28-71).  Rank 0 of the children prints the ONE JSON line on the inherited stdout.  Returns when there
+    is nothing to do (N = 1, or the ranks were already started by torchrun / the driver: WORLD_SIZE is set)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if args.stub_step_ms is None:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: device {n_dev} not present ({n_dev} GPU(s) visible on this node)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def timed_loop(run, sync, warmup, steps):
+    """W untimed warm-up steps, then EXACTLY K steps between two (barrier + device synchronise) fences.
+    Returns (elapsed seconds on this rank, host enqueue seconds, seconds to enqueue the first timed step, last result)."""
+    last = None
+    for i in range(warmup):
+        last = run(i)
+    sync()
+    log("warm-up done; timing")
+    t0 = time.perf_counter()
+    t_first = None
+    for i in range(warmup, warmup + steps):
+        last = run(i)
+        if t_first is None:   # the first step is enqueued against an idle GPU: pure host cost, no queue back-pressure
+            t_first = time.perf_counter() - t0
+    host_enqueue = time.perf_counter() - t0
+    sync()
+    return time.perf_counter() - t0, host_enqueue, t_first, last
+
+
+def max_over_ranks(x, world, device):
+    if world <= 1:
+        return float(x)
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return float(t.item())
+
+
+def stub_main(args):
+    """Launcher rehearsal without a GPU (tests/test_bench_launch.py): the same argument handling, self-launch, rendezvous,
+    fences, max-over-ranks timing and one-line report as the real run, over a gloo group, with the step replaced by a
+    sleep of --stub-step-ms plus one small all-reduce.  `data` says "stub": this line is never a measurement."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch or WORKLOADS[args.workload]["batch"]
+    buf = torch.ones(64)
+
+    def run(i):
+        time.sleep(args.stub_step_ms * 1e-3 * (1.0 + 0.5 * rank))   # rank r is slower: the report must carry the MAX
+        if world > 1:
+            torch.distributed.all_reduce(buf)
+        return i
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+
+    elapsed, _, _, _ = timed_loop(run, sync, args.warmup, args.steps)
+    elapsed = max_over_ranks(elapsed, world, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "V-JEPA pretrain clips/sec (fwd+bwd+EMA)", "value": round(B * world * args.steps / elapsed, 3),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "stub",
+            "config": {"workload": "launcher rehearsal (sleep)", "global_batch": B * world, "per_gpu_batch": B,
+                       "parallelism": f"dp{world}"}, "roofline": None, "cpu_baseline": None}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,18 +286,24 @@ def main():
                          "prefetcher (engine/input.py); reported on stderr, never as `value`")
     ap.add_argument("--gemm-csv", default=None, help="write one line per GEMM / attention launch of the roofline pass")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--stub-step-ms", type=float, default=None, help=argparse.SUPPRESS)   # launcher test: see stub_main()
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.workload)), flush=True)
         return
+    self_launch(args)            # --gpus N > 1 outside a launcher: does not return
+    if args.stub_step_ms is not None:
+        return stub_main(args)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the V-JEPA step runs only in libvjepa_hip.so (no CPU path)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: device {local_rank} not present ({torch.cuda.device_count()} GPU(s) visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("VJ_FORCE_DP", "0") == "1":
@@ -244,31 +345,23 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    last = None
-    for i in range(args.warmup):
-        last = run(i)
-    sync()
-    log("warm-up done; timing")
-    t0 = time.perf_counter()
-    t_first = None
-    for i in range(args.warmup, n_total):
-        last = run(i)
-        if t_first is None:   # the first step is enqueued against an idle GPU: pure host cost, no queue back-pressure
-            t_first = time.perf_counter() - t0
-    host_enqueue = time.perf_counter() - t0
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed, host_enqueue, t_first, last = timed_loop(run, sync, args.warmup, args.steps)
     log(f"host enqueue time {1e3 * host_enqueue / args.steps:.1f} ms/step incl. queue back-pressure, "
         f"{1e3 * t_first:.1f} ms for the first step (GPU step {1e3 * elapsed / args.steps:.1f} ms)")
+    dp_info = None
     if trainer.reducer.enabled:   # self-diagnosis of the scaling run: how long the compute stream waited on RCCL
         ex = trainer.reducer.exposed_ms()
         if ex is not None:
             log(f"exposed communication (compute stream blocked in reducer.finish): {ex:.2f} ms/step over the last "
                 f"{trainer.reducer.exposed_samples} steps")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+            ex = max_over_ranks(ex, world, device)
+        dp_info = {"ranks": world, "backend": "rccl via " + ("vj_comm_* (C ABI)" if trainer.reducer._capi else "torch.distributed"),
+                   "layer_buckets": len(trainer.reducer.buckets), "tail_ranges": len(trainer.reducer.tail),
+                   "grad_bytes_per_step": int(trainer.arena.total * 4),
+                   "exposed_comm_ms_per_step": None if ex is None else round(ex, 3),
+                   "exposed_comm_note": "time the compute stream waited for the gradient collectives in reducer.finish(), "
+                                        "max over ranks, mean of the last steps; DESIGN.md section 7 budgets <= 2 ms"}
+    elapsed = max_over_ranks(elapsed, world, device)
     loss = last.loss
     B = wl["batch"]
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps -> {B * world * args.steps / elapsed:.2f} clips/s, loss {loss:.5f}")
@@ -340,7 +433,24 @@ def main():
         side.enabled = True
         chain.prof_enable(False)
         timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
-        fam = chain.prof_collect(args.gemm_csv)
+        import tempfile
+        csv_path = args.gemm_csv or os.path.join(tempfile.gettempdir(), f"vj_bench_launches_{os.getpid()}.csv")
+        fam = chain.prof_collect(csv_path)
+        # per-epilogue split of the C chains' GEMM launches (csv: family,tag,m,n,k,us; family 0 = GEMM, tag 0 = bf16 epilogue
+        # with optional bias / residual = gemm_nt_8phase_persist_kernel<0>, the kernel with the largest share of the step)
+        dom = dict(launches=0, ms=0.0, flop=0.0, bytes=0.0)
+        with open(csv_path) as fcsv:
+            next(fcsv)
+            for ln in fcsv:
+                f_, tag, m, n, k, us = ln.split(",")
+                if f_ == "0" and tag == "0":
+                    m, n, k = int(m), int(n), int(k)
+                    dom["launches"] += 1
+                    dom["ms"] += float(us) * 1e-3
+                    dom["flop"] += 2.0 * m * n * k
+                    dom["bytes"] += 2.0 * (m * k + n * k + m * n)   # A and B read once, C written once (bf16)
+        if not args.gemm_csv:
+            os.unlink(csv_path)
         for name, evs in timers.items():
             f = fam.setdefault(name, dict(launches=0, ms=0.0, flop=0.0))
             f["launches"] += len(evs)
@@ -351,33 +461,47 @@ def main():
         log(f"roofline pass: {json.dumps({k: dict(v, tflops=round(v['flop'] / v['ms'] / 1e9, 1)) for k, v in fam.items()})}")
         # HBM bytes per launch of the dominant kernel: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
         # correction + WRITE_SIZE), committed under profiles/ -- counters cannot be collected from inside this process
+        DOM = "gemm_nt_8phase_persist_kernel<0>"
         traffic, traffic_src = None, None
-        for pmc_name in ("r03_hbm_pmc.json", "r02_hbm_pmc.json", "r01_hbm_pmc.json"):
+        for pmc_name in ("r04_hbm_pmc.json", "r03_hbm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and args.workload == "vitl16":
                 with open(pmc) as fjs:
                     tab = json.load(fjs)
-                ent = tab.get("gemm_nt_8phase_persist_kernel<0>") or tab.get("gemm_nt_8phase_kernel<0>")
+                ent = tab.get(DOM)
                 if ent:
                     traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/" + pmc_name
                     break
+        dom_ach = dom["flop"] / (dom["ms"] * 1e-3) if dom["ms"] > 0 else 0.0
+        dom_bytes = dom["bytes"] / dom["launches"] if dom["launches"] else None
+        whole = {"achieved": round(step_tflops, 2), "frac": round(step_tflops * 1e12 / MFMA_BF16_PEAK, 4),
+                 "tflop_per_clip": round(fl / (args.steps * B) / 1e12, 3)}
         roof = {"bound": "mfma",
-                "kernel": "bf16 MFMA GEMM family (gemm_nt_8phase_persist_kernel: persistent 256x256 staggered 8-phase, "
-                          "cross-tile LDS-DMA prefetch; gemm_tn_8phase_kernel: transpose-free weight gradients, the four of a "
-                          "block in one launch; MFMA 16x16x32); traffic = dominant kernel "
-                          "gemm_nt_8phase_persist_kernel<0>",
-                "achieved": round(ach / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
-                "traffic_source": traffic_src,
-                "launches_per_step": g["launches"] // n_inst,
-                "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
-                "gemm_ms_per_step": round(g["ms"] / n_inst, 2),
+                "kernel": "whole V-JEPA step (matmul FLOPs of target forward + context / predictor forward + backward over the "
+                          "timed region, two-stream execution); sub-objects from the instrumented single-stream pass",
+                "achieved": whole["achieved"], "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": whole["frac"],
+                "traffic": traffic, "traffic_unit": f"HBM bytes per launch of {DOM} (PMC)", "traffic_source": traffic_src,
+                "whole_step": whole,
+                "gemm_family": {"kernels": "gemm_nt_8phase_persist_kernel<0|1|2> (persistent 256x256 staggered 8-phase NT, "
+                                           "cross-tile LDS-DMA prefetch), gemm_tn_8phase_kernel (transpose-free weight gradients, "
+                                           "the four of a block in one launch); MFMA 16x16x32 bf16",
+                                "achieved": round(ach / 1e12, 2), "frac": round(ach / MFMA_BF16_PEAK, 4),
+                                "launches_per_step": g["launches"] // n_inst,
+                                "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+                                "ms_per_step": round(g["ms"] / n_inst, 2)},
+                "dominant_kernel": {"name": DOM, "achieved": round(dom_ach / 1e12, 2),
+                                    "frac": round(dom_ach / MFMA_BF16_PEAK, 4),
+                                    "launches_per_step": dom["launches"] // n_inst,
+                                    "avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
+                                    "ms_per_step": round(dom["ms"] / n_inst, 2),
+                                    "algorithmic_bytes_per_launch": None if dom_bytes is None else round(dom_bytes),
+                                    "traffic_bytes_per_launch": traffic,
+                                    "traffic_over_algorithmic": (round(traffic / dom_bytes, 3)
+                                                                 if traffic and dom_bytes else None)},
                 "attn_fwd": {"tflops": round(fam["attn_fwd"]["flop"] / fam["attn_fwd"]["ms"] / 1e9, 1),
                              "ms_per_step": round(fam["attn_fwd"]["ms"] / n_inst, 2)},
                 "attn_bwd": {"tflops": round(fam["attn_bwd"]["flop"] / fam["attn_bwd"]["ms"] / 1e9, 1),
-                             "ms_per_step": round(fam["attn_bwd"]["ms"] / n_inst, 2)},
-                "whole_step": {"achieved": round(step_tflops, 2), "frac": round(step_tflops * 1e12 / MFMA_BF16_PEAK, 4),
-                               "tflop_per_clip": round(fl / (args.steps * B) / 1e12, 3)}}
+                             "ms_per_step": round(fam["attn_bwd"]["ms"] / n_inst, 2)}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -394,6 +518,8 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if dp_info is not None:
+            line["dp"] = dp_info
         if input_edge is not None:
             line["input_edge"] = input_edge
         print(json.dumps(line), flush=True)

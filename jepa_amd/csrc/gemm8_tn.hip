@@ -22,6 +22,7 @@
 //
 // Split-K over the token tiles and the fp32 epilogue are shared with the NT kernels (gemm_common.hpp).
 #include <type_traits>
+#include <mutex>
 #include "gemm_common.hpp"
 #include "options.hpp"
 
@@ -367,11 +368,17 @@ __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, in
                                      float alpha, float beta);   // gemm.hip
 
 static int tn_zero_row(const bf16_t** out) {
+  // one buffer per device, set up once per device under a mutex (two host threads must not both allocate); the memset
+  // is followed by a device synchronise so that it is ordered before ANY stream's first TN launch (hipMemset runs on the
+  // legacy null stream, which non-blocking side streams do not wait for)
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
   bf16_t*& z = g_zero_rows[vj_device_slot()];
   if (z == nullptr) {
     bf16_t* q = nullptr;
     hipError_t e = hipMalloc((void**)&q, 256);
     if (e == hipSuccess) e = hipMemset(q, 0, 256);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
       vj_set_error("vj_gemm_bf16_tn_splitk: zero row allocation failed: %s", hipGetErrorString(e));
       return (int)e;

@@ -10,12 +10,13 @@
 namespace {
 struct OptDef {
   const char* name;
-  int dflt;
+  int dflt, lo, hi;   // accepted range (inclusive): a value outside it is rejected, never silently mapped to some kernel
 };
 const OptDef kDefs[VJ_OPT_COUNT] = {
-    {"gemm_fwd_flags", 0}, {"gemm_dgrad_flags", 0}, {"gemm_4w", 0},         {"gemm_persist", 1},
-    {"wgrad_tn", 1},       {"wgrad_group", 1},      {"wgrad_slow_issue", 0}, {"attn_dkdv_kt", 0},
-    {"gemm_dbg", 0},
+    {"gemm_fwd_flags", 0, 0, 0xffff}, {"gemm_dgrad_flags", 0, 0, 0xffff}, {"gemm_4w", 0, 0, 2},
+    {"gemm_persist", 1, 0, 2},        {"wgrad_tn", 1, 0, 1},              {"wgrad_group", 1, 0, 1},
+    {"wgrad_slow_issue", 0, 0, 1},    {"attn_dkdv_kt", 0, 0, 2},          {"gemm_dbg", 0, 0, 3},
+    {"attn_softmax", 1, 0, 1},        {"bias_fuse", 1, 0, 1},             {"gelu_poly", 1, 0, 1},
 };
 std::atomic<int> g_val[VJ_OPT_COUNT];
 std::once_flag g_once;
@@ -26,7 +27,13 @@ void init_once() {
       std::string env = "VJ_";
       for (const char* c = kDefs[i].name; *c; c++) env.push_back((char)toupper((unsigned char)*c));
       const char* e = getenv(env.c_str());
-      g_val[i].store(e ? atoi(e) : kDefs[i].dflt, std::memory_order_relaxed);
+      int v = e ? atoi(e) : kDefs[i].dflt;
+      if (v < kDefs[i].lo || v > kDefs[i].hi) {
+        fprintf(stderr, "libvjepa_hip: %s=%d outside [%d, %d], using the default %d\n", env.c_str(), v, kDefs[i].lo,
+                kDefs[i].hi, kDefs[i].dflt);
+        v = kDefs[i].dflt;
+      }
+      g_val[i].store(v, std::memory_order_relaxed);
     }
   });
 }
@@ -40,6 +47,7 @@ int find(const char* name) {
 
 int vj_opt(int id) {
   init_once();
+  if (id < 0 || id >= VJ_OPT_COUNT) return 0;
   return g_val[id].load(std::memory_order_relaxed);
 }
 
@@ -47,6 +55,8 @@ extern "C" int vj_set_option(const char* name, int value) {
   init_once();
   const int i = find(name);
   VJ_CHECK_ARG(i >= 0, "vj_set_option: unknown option '%s'", name ? name : "(null)");
+  VJ_CHECK_ARG(value >= kDefs[i].lo && value <= kDefs[i].hi, "vj_set_option: %s=%d outside [%d, %d]", name, value,
+               kDefs[i].lo, kDefs[i].hi);
   g_val[i].store(value, std::memory_order_relaxed);
   return 0;
 }

@@ -4,6 +4,9 @@
 // otherwise); they exist so that A/B measurements can be interleaved inside ONE process on one GPU (tools/abab.py):
 // box-to-box and thermal drift on MI355X is larger than most kernel-level deltas.  Initial values come from the
 // environment variable of the same name in upper case with a VJ_ prefix (VJ_GEMM_4W=1 ...), read once.
+// Every switch has an accepted value range (options.cpp): vj_set_option rejects anything else.  Switches are process-global and
+// read at ENQUEUE time: change them only BETWEEN optimisation steps (changing e.g. wgrad_group between the micro-batches of
+// one step would change the fp32 summation order mid-accumulation).
 #pragma once
 
 enum VjOpt {
@@ -20,6 +23,14 @@ enum VjOpt {
   VJ_OPT_WGRAD_SLOW_ISSUE,     // 1: the TN kernel's K loop issues its parts through the generic address path (A/B only)
   VJ_OPT_ATTN_DKDV_KT,         // 16-key tiles per wave in the attention dK/dV kernel: 0 (default) per head-dim class, 1 / 2 forced
   VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)
+  VJ_OPT_ATTN_SOFTMAX,         // 1 (default, round 4): attention kernels with the soft-max scale folded into the stationary operand
+                               // and the score accumulators seeded with -max / -lse (no per-score FMA, no per-tile row maximum);
+                               // 0: the round-3 kernels (results agree to bf16 rounding, not bitwise)
+  VJ_OPT_BIAS_FUSE,            // 1 (default, round 4): qkv / fc1 bias gradients from column partials written by the kernels that
+                               // PRODUCE dY (attention backward, fc2-dgrad epilogue), one reduction launch per block;
+                               // 0: stand-alone column-sum kernels re-reading dY
+  VJ_OPT_GELU_POLY,            // 1 (default, round 4): erf of the no-backward GELU epilogue by an odd minimax polynomial (no v_rcp /
+                               // v_exp); 0: Abramowitz-Stegun 7.1.26
   VJ_OPT_COUNT
 };
 

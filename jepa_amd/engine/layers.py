@@ -113,7 +113,7 @@ from ..hip.lib import get_option as _get_option  # noqa: E402
 
 
 def _tn_ok(n_out: int, k_in: int) -> bool:
-    return _get_option("wgrad_tn") == 1 and n_out % 8 == 0 and k_in % 8 == 0
+    return _get_option("wgrad_tn") != 0 and n_out % 8 == 0 and k_in % 8 == 0   # as chain.hip: any non-zero value is "on"
 
 
 def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0, bias_done: bool = False):
@@ -124,14 +124,16 @@ def _wgrad(dy, x_in, lw: LinearW, alpha: float, beta: float = 0.0, bias_done: bo
             ops.colsum(dy, lw.gb, alpha=alpha, accumulate=acc)
         ops.gemm_wgrad_tn(dy, x_in, lw.gw, alpha=alpha, beta=beta)
         return
-    dyT = ops.transpose_colsum(dy, lw.gb, alpha=alpha, accumulate=acc) if lw.gb is not None else ops.transpose(dy)
+    # (bias_done: the LayerNorm backward already wrote lw.gb -- no second column sum, exactly as chain.hip wgrad() nulls gb)
+    need_cs = lw.gb is not None and not bias_done
+    dyT = ops.transpose_colsum(dy, lw.gb, alpha=alpha, accumulate=acc) if need_cs else ops.transpose(dy)
     xT = ops.transpose(x_in)
     ops.gemm_wgrad(dyT, xT, lw.gw, alpha=alpha, beta=beta)
 
 
 def _group_ok(bw) -> bool:
     """Option wgrad_group: the four weight gradients of a block as one vj_gemm_bf16_tn_grouped launch (as vj_blocks_bwd)."""
-    return (_get_option("wgrad_tn") == 1 and _get_option("wgrad_group") != 0 and
+    return (_get_option("wgrad_tn") != 0 and _get_option("wgrad_group") != 0 and
             all(d % 8 == 0 for lw in (bw.qkv, bw.proj, bw.fc1, bw.fc2) for d in lw.gw.shape))
 
 
