@@ -86,6 +86,14 @@ int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
                     void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags,
                     vj_stream_t stream);
+/* fc2 dgrad (epilogue 2) that also produces the bias gradient of fc1 (autograd of Mlp.fc1's bias, modules.py:31-34: the sum
+ * over tokens of the dY this GEMM writes): when the persistent 256 x 256 kernel takes the problem, colpart
+ * [vj_gemm_colsum_rows(M)][N] receives fp32 column sums of C (before the bf16 rounding) per (row tile, wave row) and *fused = 1;
+ * otherwise the plain GEMM runs and *fused = 0 (sum C with vj_colsum_bf16).  C is bit-identical to vj_gemm_bf16_nt's. */
+int64_t vj_gemm_colsum_rows(int64_t M);
+int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
+                                 int64_t N, int64_t K, const void* aux_in, int64_t ldaux, float* colpart,
+                                 int64_t colpart_rows, int flags, int* fused, vj_stream_t stream);
 /* wgrad form of the same GEMM: C (fp32) = alpha*A*B^T + beta*C where K (= tokens) is long and the [M,N] tile grid
  * alone cannot fill 256 CUs: K is split across workgroups, partials combined deterministically from ws
  * (ws_bytes >= M*N*4; more workspace allows more slices). */
@@ -127,6 +135,15 @@ int vj_colsum_bf16(const void* in, int64_t M, int64_t N, int64_t ld, int64_t gro
                    float* out, float alpha, float beta, void* ws, int64_t ws_bytes, vj_stream_t stream);
 int vj_reduce_partials(const float* part, float* out, int64_t P, int64_t N, float alpha, float beta,
                        vj_stream_t stream);
+/* n <= 16 such reductions in ONE launch: out_s[n] = alpha * sum_p part_s[p*stride_s + n] + beta * out_s[n]; same summation
+ * order (hence the same bits) as vj_reduce_partials.  The backward of a Block ends with one of these: LayerNorm dgamma / dbeta,
+ * the proj / fc2 bias sums (modules.py:34,76) and the qkv / fc1 bias partials of the kernels that produce their dY. */
+typedef struct vj_reduce_seg {
+  const float* part; /* [P, stride] fp32 partials */
+  float* out;        /* [N] */
+  int64_t P, N, stride;
+} vj_reduce_seg_t;
+int vj_reduce_segments(const vj_reduce_seg_t* segs, int64_t n_segs, float alpha, float beta, vj_stream_t stream);
 
 /* ---- attention ----------------------------------------------------------------------------------------------
  * F.scaled_dot_product_attention(q,k,v) (modules.py:66-69): dense, non-causal, scale = head_dim^-0.5.
@@ -140,6 +157,15 @@ int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H);
 /* dqkv [B,S,3,H,hd] <- (dout [B,S,H*hd], saved qkv, o, lse2) */
 int vj_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B,
                 int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, vj_stream_t stream);
+/* the same, plus the column sums of dqkv over this [B,S] segment as fp32 partials -- the qkv bias gradient (autograd of
+ * Attention.qkv's bias, modules.py:63) from the kernels that produce dqkv instead of a second pass over it:
+ * colq [rows_q][H*hd] (dQ kernel: one row per (sample, 128-query block)), colkv [rows_kv][2*H*hd] (dK/dV kernel: one row per
+ * (sample, key block)); row counts from vj_attn_bwd_colsum_rows (they depend on the attn_dkdv_kt option); every element is
+ * written; dqkv is bit-identical to vj_attn_bwd's.  Reduce with vj_reduce_segments. */
+int vj_attn_bwd_colsum_rows(int64_t B, int64_t S, int64_t hd, int64_t* rows_q, int64_t* rows_kv);
+int vj_attn_bwd_colsum(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B,
+                       int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, float* colq,
+                       float* colkv, vj_stream_t stream);
 
 /* ---- cross-attention of a few learned queries against frozen-encoder tokens (attentive probe, row f4 widened) ------
  * CrossAttention.forward (src/models/utils/modules.py:140-157) as used by CrossAttentionBlock (modules.py:177-181) inside
@@ -263,7 +289,12 @@ int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads);
  * gradients wait on it.  on_layer_done(user, l) (nullable) is called from the enqueueing thread as soon as block l's
  * backward has been enqueued on both streams (gradient-bucket launch hook, DDP equivalent of train.py:295-297).
  * flags bit0: transpose-free weight gradients (vj_gemm_bf16_tn_splitk; with option "wgrad_group" the four of a block
- * in one vj_gemm_bf16_tn_grouped launch once the block's last dY exists). */
+ * in one vj_gemm_bf16_tn_grouped launch once the block's last dY exists).
+ * flags bit1: the caller already wrote the LAST block's fc2 bias gradient (the column sums of dout; it comes out of the
+ * LayerNorm backward that produced dout, vj_layernorm_bwd_colsum) -- with the transpose-free route only.
+ * With the transpose-free route and option "bias_fuse" (default) the bias gradients of qkv and fc1 come from column partials of
+ * the kernels that produce dqkv / du (vj_attn_bwd_colsum, vj_gemm_bf16_nt_dgelu_colsum) and every partial reduction of a block
+ * (both LayerNorms', those two) is ONE vj_reduce_segments launch at the end of the block. */
 int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, const void* dout, void* dx_out, int64_t M,
                   int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float alpha, float beta_acc,
                   const void* save_ws, int64_t save_ws_bytes, void* tmp_ws, int64_t tmp_ws_bytes, int flags,

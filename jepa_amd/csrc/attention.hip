@@ -61,6 +61,30 @@ __device__ __forceinline__ void raw_barrier() {   // s_barrier without the vmcnt
 
 #define DEFER_LOG2 5.0f  // forward softmax: rescale O only when a row max grows by more than 2^5
 
+// ---- round 4: "seeded" soft-max (template parameter SM = 1; SM = 0 keeps the round-3 arithmetic for A/B) ----------------
+// The attention kernels are bound by vector-instruction issue and the matrix and vector pipes of a SIMD add
+// (profiles/r03_valu_mfma_probe.md), so only REMOVING vector instructions per score helps.  Per score the round-3 kernels
+// spend: 1/2 v_pk_fma (s*sc - m), 1 v_exp, 1/2 v_max3 (forward), 1/2 v_pk_add (row sum), 1/2 v_cvt_pk.  With SM = 1:
+//   * the soft-max scale scale*log2(e) is folded into the STATIONARY operand of the score product (Q in the forward and in
+//     dQ, K in dK/dV), once per workgroup: bf16(c * x) -- one more bf16 rounding of that operand;
+//   * the score accumulators START at -m_run (forward) / -lse2[q] (backward), so the MFMA delivers s - m and v_exp_f32
+//     reads the accumulator directly: no per-score FMA;
+//   * the forward does not compute a row maximum per tile.  The running base m_run is kept 2^SM_HEADROOM above the largest
+//     score seen when it was last set, so every probability is normally <= 2^-SM_HEADROOM; a tile needs a new base only if
+//     some probability reaches 2.0, i.e. bit 14 (the top exponent bit) of a packed bf16 P word is set: the test is the OR of
+//     the eight packed words of a row against 0x40004000 (v_or3_b32: 5 plain instructions per 16 scores instead of 8 v_max3
+//     + two cross-lane exchanges).  OR >= max for unsigned integers, so "bit clear" PROVES every P < 2 (inf / NaN have the
+//     bit set and take the slow path, which computes the exact maximum and re-bases exactly like the round-3 code);
+//   * head_dim 24 (the predictor; 32-wide class): column 24 of the V image holds 1.0, so the P.V MFMA accumulates the row
+//     sum of the bf16-rounded P in output column 24 -- the row sums leave the vector pipe too (template parameter PSUM).
+#define SM_HEADROOM 5.0f
+__device__ __forceinline__ bf16x8_t scale_frag(bf16x8_t f, float c) {
+  u32x4_t w = __builtin_bit_cast(u32x4_t, f);
+#pragma unroll
+  for (int j = 0; j < 4; j++) w[j] = cvt_pk_bf16(bf_lo(w[j]) * c, bf_hi(w[j]) * c);
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+
 // 16-byte-chunk XOR key of a row.  128/256-byte rows (hd 64/128): row & 7.  64- and 192-byte rows (hd 32 / 96): rows r
 // and r+4 start on the same banks, so the key must separate the four row quads that one ds_read_b128 lane group
 // ({0-3,12-15} of one g with {4-11} of the next) or one ds_read_b64_tr_b16 half (rows 0-7) touches: quads 0,1,2,3 get
@@ -440,6 +464,263 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
 }
 
 // =============================================================================================================
+// forward, round 4 ("seeded" soft-max, see SM_HEADROOM above): same tiling, staging and MFMA layout as attn_fwd_kernel
+// =============================================================================================================
+template <int HDP, int QT, int NBUF, bool PSUM>
+__global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                          float* __restrict__ lse2, int B, int S, int H, int hd,
+                                                          float sc, int nqb) {
+  constexpr int NT = 8 * 64 / QT;
+  using RT = RowTile<HDP, NT>;
+  constexpr int DIST = NBUF - 1;
+  static_assert(RT::CAN_FULL || NT == 512, "tile items must be a multiple of the workgroup size");
+  static_assert(!PSUM || (HDP == 32 && RT::CAN_FULL && RT::NIT == 1), "row sums on the pad column: 32-wide class, one DMA item per thread");
+  constexpr int NDMA = RT::CAN_FULL ? RT::NIT : 1;
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * RT::BYTES];
+  const TrFrag<HDP> trf(threadIdx.x & 63);
+  constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = logical % nqb, bh = logical / nqb;
+  const int h = bh % H, b = bh / H;
+  const int64_t rs = (int64_t)3 * H * hd;
+  const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
+  const bf16_t* kbase = qbase + (int64_t)H * hd;
+  const int q0 = qb * 128 + w * (16 * QT);
+
+  // Q fragments carry the soft-max scale: bf16(q * scale * log2 e), once per workgroup
+  bf16x8_t qf[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; qt++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int q = q0 + qt * 16 + li, d0 = ks * 32 + 8 * g;
+      qf[qt][ks] = scale_frag(load_frag_global(qbase + (int64_t)q * rs + d0, q < S && d0 < hd), sc);
+    }
+
+  f32x4_t oacc[QT][DT];
+#pragma unroll
+  for (int qt = 0; qt < QT; qt++)
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) oacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // mrun: the base the scores are measured against (s - mrun comes out of the matrix pipe); 0 until the first tile set it
+  float mrun[QT], lrun[QT];
+  f32x4_t seed[QT];            // {-mrun} x 4: srcC of the first score MFMA of every key tile
+#pragma unroll
+  for (int qt = 0; qt < QT; qt++) {
+    mrun[qt] = 0.f;
+    lrun[qt] = 0.f;
+    seed[qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nt = (S + 63) / 64;
+  int dma_row[NDMA];
+  unsigned dma_voff[NDMA], dma_col2[NDMA];
+  const bool dma_on = RT::CAN_FULL || tid < 64 * RT::CHP;
+  bool vpad = false;           // PSUM: this thread's DMA item is the pad chunk (columns >= hd) of its V row
+#pragma unroll
+  for (int it = 0; it < NDMA; it++) {
+    const int item = RT::CAN_FULL ? tid + it * NT : (tid < 64 * RT::CHP ? tid : 0);
+    const int row = item / RT::CHP, c = (item % RT::CHP) ^ rm_swz<HDP>(row);
+    const int col = c * 8 < hd ? c * 8 : 0;
+    if constexpr (PSUM) vpad = c * 8 >= hd;
+    dma_row[it] = row;
+    dma_col2[it] = (unsigned)col * 2u;
+    dma_voff[it] = ((unsigned)row * (unsigned)rs + (unsigned)col) * 2u;
+  }
+  if constexpr (PSUM) {
+    // the pad chunk of every V row: column hd = 1.0, the rest 0, written ONCE into every ring buffer; the V DMA skips these
+    // lanes (exec-masked), so the chunk survives every tile.  P.V then accumulates sum_k P[q][k] in output column hd.
+    if (vpad) {
+      const u32x4_t one = {0x00003F80u, 0u, 0u, 0u};
+#pragma unroll
+      for (int d = 0; d < NBUF; d++) *(u32x4_t*)(smem + d * 2 * RT::BYTES + RT::BYTES + tid * 16) = one;
+    }
+  }
+  const int64_t v_off = (int64_t)H * hd;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned rs2 = (unsigned)rs * 2u;
+  auto issue = [&](const int tile, const int buf_off, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    char* kb = smem + buf_off;
+    const bf16_t* kt = kbase + (int64_t)tile * 64 * rs;   // uniform
+    const bf16_t* vt = kt + v_off;
+#pragma unroll
+    for (int it = 0; it < NDMA; it++) {
+      unsigned vo;
+      if constexpr (FULL) {
+        vo = dma_voff[it];
+      } else {
+        const int last = S - 1 - tile * 64;
+        const int r = dma_row[it] < last ? dma_row[it] : last;
+        vo = (unsigned)r * rs2 + dma_col2[it];
+      }
+      char* dst = kb + (it * NT + wu * 64) * 16;
+      if (dma_on) {
+        dma16_sv(kt, vo, lds_addr(dst));
+        if constexpr (PSUM) {
+          if (!vpad) dma16_sv(vt, vo, lds_addr(dst + RT::BYTES));   // never all lanes of a wave: one pad chunk per 4 lanes
+        } else {
+          dma16_sv(vt, vo, lds_addr(dst + RT::BYTES));
+        }
+      }
+    }
+  };
+  constexpr int BUFB = 2 * RT::BYTES, RINGB = NBUF * BUFB;
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll
+  for (int d = 0; d < DIST; d++)
+    if (d < nt) issue(d, d * BUFB, std::false_type{});
+  int cur_off = 0, nxt_off = DIST * BUFB;
+
+  // FIRST: tile 0 -- the base is unknown (seed 0), the exact-maximum path runs unconditionally and nothing is rescaled.
+  auto iter = [&](const int t, auto fast_tag, auto first_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value, FIRST = decltype(first_tag)::value;
+    const int k0 = t * 64;
+    char* k_lds = smem + cur_off;
+    char* v_lds = k_lds + RT::BYTES;
+    if (DIST >= 2 && (FAST || t + 1 < nt)) wait_vmcnt<2 * NDMA>();
+    else wait_vmcnt<0>();
+    raw_barrier();
+    if constexpr (FAST) issue(t + DIST, nxt_off, std::true_type{});
+    else if (t + DIST < nt) issue(t + DIST, nxt_off, std::false_type{});
+    cur_off = cur_off + BUFB == RINGB ? 0 : cur_off + BUFB;
+    nxt_off = nxt_off + BUFB == RINGB ? 0 : nxt_off + BUFB;
+    // ---- S^T - m = K (cQ)^T - m : sacc[qt][kt] holds (s2 - mrun)[key = kt*16 + 4g + r][q = li] ----
+    f32x4_t sacc[QT][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        const bf16x8_t kf = RT::frag(k_lds, kt * 16 + li, ks * 4 + g);
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++)
+          sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], ks == 0 ? seed[qt] : sacc[qt][kt], 0, 0, 0);
+      }
+    if constexpr (!FAST) {
+      if (k0 + 64 > S) {  // wave-uniform: only the last tile can hold padded keys
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++)
+#pragma unroll
+          for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (k0 + kt * 16 + 4 * g + r >= S) sacc[qt][kt][r] = -INFINITY;
+      }
+    }
+    u32x4_t pw[QT][2];
+    f32x2_t ls2[QT];
+    // exponentials straight from the accumulators, packed to bf16; row-sum partials unless the pad column provides them
+    auto exps = [&](const int qt) __attribute__((always_inline)) {
+      ls2[qt] = (f32x2_t){0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++) {
+            const int kt = 2 * c + k2;
+            const f32x2_t e = {__builtin_amdgcn_exp2f(sacc[qt][kt][2 * hf]), __builtin_amdgcn_exp2f(sacc[qt][kt][2 * hf + 1])};
+            if constexpr (!PSUM) ls2[qt] += e;
+            pw[qt][c][2 * k2 + hf] = cvt_pk_bf16(e[0], e[1]);
+          }
+    };
+    // ONE wave-uniform decision per tile (all rows of the wave): the common path is a single straight-line block
+    bool rebase = FIRST;
+    if constexpr (!FIRST) {
+      uint32_t orw = 0;
+#pragma unroll
+      for (int qt = 0; qt < QT; qt++) {
+        exps(qt);
+        orw |= (pw[qt][0][0] | pw[qt][0][1] | pw[qt][0][2]) | (pw[qt][0][3] | pw[qt][1][0] | pw[qt][1][1]) |
+               (pw[qt][1][2] | pw[qt][1][3]);
+      }
+      rebase = __any((orw & 0x40004000u) != 0);   // some probability of some row of this wave reached 2.0
+    }
+    if (rebase) {
+#pragma unroll
+      for (int qt = 0; qt < QT; qt++) {
+        // exact row maximum (relative to the current base), new base = old base + max(mx + headroom, 0) -- never lowered
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) mx = fmaxf(mx, sacc[qt][kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float shift = mx + SM_HEADROOM;
+        if constexpr (!FIRST) {
+          shift = fmaxf(shift, 0.f);
+          const float alpha = __builtin_amdgcn_exp2f(-shift);
+          lrun[qt] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; dt++) oacc[qt][dt] *= alpha;
+        }
+        mrun[qt] += shift;
+        seed[qt] = (f32x4_t){-mrun[qt], -mrun[qt], -mrun[qt], -mrun[qt]};
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++) sacc[qt][kt] -= (f32x4_t){shift, shift, shift, shift};
+        exps(qt);
+      }
+    }
+    bf16x8_t pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+      if constexpr (!PSUM) lrun[qt] += ls2[qt][0] + ls2[qt][1];
+      pf[qt][0] = __builtin_bit_cast(bf16x8_t, pw[qt][0]);
+      pf[qt][1] = __builtin_bit_cast(bf16x8_t, pw[qt][1]);
+    }
+    // ---- O^T += V^T P^T : oacc[qt][dt] holds O^T[d = dt*16 + 4g + r][q = li] (PSUM: d = hd is the row sum) ----
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const bf16x8_t vf = trf.load(v_lds, c * 32, dt * 16);
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++)
+          oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
+      }
+  };
+  const int nfull = RT::CAN_FULL ? S / 64 : 0;
+  const int t_fast = nfull - DIST > 0 ? nfull - DIST : 0;
+  int t = 1;
+  if (t_fast > 0) iter(0, std::true_type{}, std::true_type{});
+  else iter(0, std::false_type{}, std::true_type{});
+  for (; t < t_fast; t++) iter(t, std::true_type{}, std::false_type{});
+  for (; t < nt; t++) iter(t, std::false_type{}, std::false_type{});
+
+#pragma unroll
+  for (int qt = 0; qt < QT; qt++) {
+    float l;
+    if constexpr (PSUM) {
+      // column hd = 24 of O^T: tile dt = 1, rows 4g + r = 8 -> lanes g == 2, element 0; broadcast to the row's four lane groups
+      l = __shfl(oacc[qt][1][0], 32 + li, 64);
+    } else {
+      l = lrun[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
+    const int q = q0 + qt * 16 + li;
+    if (q < S) {
+      const float inv = 1.0f / l;
+      bf16_t* op = o + ((int64_t)b * S + q) * ((int64_t)H * hd) + (int64_t)h * hd;
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++) {
+        const int d = dt * 16 + 4 * g;
+        if (d < hd) {
+          u32x2_t ov;
+          ov[0] = cvt_pk_bf16(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv);
+          ov[1] = cvt_pk_bf16(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv);
+          *(u32x2_t*)(op + d) = ov;
+        }
+      }
+      if (g == 0 && lse2) lse2[((int64_t)b * H + h) * S + q] = mrun[qt] + log2f(l);
+    }
+  }
+}
+
+// =============================================================================================================
 // backward, part 1: dK, dV.  One workgroup per 64*KT-key block (16*KT keys per wave), loop over 64-query tiles.
 //   S = Q K^T (lane: S[q = qt*16+4g+r][key = li]),  P = exp2(S*sc - lse2[q]),  dP = dO V^T,
 //   dS = P (dP - delta[q]),  dV^T += dO^T P,  dK^T += Q^T dS  (then * scale)
@@ -449,13 +730,13 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
 // 16 MFMAs + the soft-max arithmetic of 16 scores per lane: the kernel is bound by LDS INSTRUCTIONS.  The Q / dO fragments
 // and their transposed reads do not depend on the key, so KT = 2 reuses every one of them for two key tiles.
 // =============================================================================================================
-template <int HDP, int KT>
+template <int HDP, int KT, bool SM>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv,
                                                             const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ lse2,
                                                             const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
-                                                            float sc, float scale, int nkb) {
+                                                            float sc, float scale, int nkb, float* __restrict__ colkv) {
   // two {Q, dO} images filled by LDS-DMA (tile t+1 lands while tile t is multiplied) + two {lse, delta} rows; one
   // barrier per tile
   constexpr int BUFB = 2 * RowTile<HDP>::BYTES;
@@ -492,6 +773,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
       const int d0 = ks * 32 + 8 * g;
       kf[kt][ks] = load_frag_global(kbase + (int64_t)key[kt] * rs + d0, key_ok[kt] && d0 < hd);
       vf[kt][ks] = load_frag_global(vbase + (int64_t)key[kt] * rs + d0, key_ok[kt] && d0 < hd);
+      // SM: K is the stationary operand of the score product here and is used for nothing else (dK contracts dS with Q):
+      // it carries the soft-max scale, bf16(k * scale * log2 e)
+      if constexpr (SM) kf[kt][ks] = scale_frag(kf[kt][ks], sc);
     }
   f32x4_t dvacc[KT][DT], dkacc[KT][DT];
 #pragma unroll
@@ -547,10 +831,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
       const float4 lse4 = *(const float4*)(lse_s + qt * 16 + 4 * g);   // queries qt*16 + 4g + {0..3}
       const float4 ndl4 = *(const float4*)(dl_s + qt * 16 + 4 * g);    // -delta of the same queries
       // the dP accumulator STARTS at -delta[q] (this lane's four rows): dP - delta comes out of the matrix pipe
+      // SM: the score accumulator starts at -lse2[q] the same way, so P = exp2(accumulator) (padded queries: -inf -> P = 0)
       f32x4_t sacc[KT], dpacc[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; kt++) {
-        sacc[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        sacc[kt] = SM ? (f32x4_t){-lse4.x, -lse4.y, -lse4.z, -lse4.w} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
         dpacc[kt] = (f32x4_t){ndl4.x, ndl4.y, ndl4.z, ndl4.w};
       }
 #pragma unroll
@@ -569,7 +854,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
           const f32x2_t sv = {sacc[kt][2 * hf], sacc[kt][2 * hf + 1]}, dpv = {dpacc[kt][2 * hf], dpacc[kt][2 * hf + 1]};
-          const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl[hf]);   // padded queries: lse = +inf -> P = 0
+          f32x2_t a = sv;
+          if constexpr (!SM) a = __builtin_elementwise_fma(sv, sc2, nl[hf]);   // padded queries: lse = +inf -> P = 0
           const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
           const f32x2_t ds = e * dpv;
           pv[kt][qt][2 * hf] = e[0];
@@ -608,6 +894,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
     }
   }
 
+  // column partials for the qkv bias gradient (colkv != nullptr): this workgroup's sum over its keys of dK | dV (fp32, before the
+  // bf16 rounding) -> colkv[b * nkb + kb][h*hd + d | H*hd + h*hd + d]; padded keys (garbage accumulators, never stored) are masked
+  if (colkv != nullptr) {
+    float ck[DT][4], cv[DT][4];
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+          a += key_ok[kt] ? dkacc[kt][dt][r] : 0.f;
+          c += key_ok[kt] ? dvacc[kt][dt][r] : 0.f;
+        }
+        ck[dt][r] = row16_sum(a);   // over the 16 keys of the lane row (li)
+        cv[dt][r] = row16_sum(c);
+      }
+    raw_barrier();   // every wave is done with the {Q, dO} images: the first 4 x 2 x HDP floats of the ring become the combine buffer
+    float* red = (float*)smem;
+    if (li == 0) {
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          red[(w * 2 + 0) * HDP + dt * 16 + 4 * g + r] = ck[dt][r];
+          red[(w * 2 + 1) * HDP + dt * 16 + 4 * g + r] = cv[dt][r];
+        }
+    }
+    raw_barrier();
+    if (tid < 2 * HDP) {
+      const int which = tid / HDP, d = tid % HDP;
+      if (d < hd) {
+        float t = red[(0 * 2 + which) * HDP + d] + red[(1 * 2 + which) * HDP + d] + red[(2 * 2 + which) * HDP + d] +
+                  red[(3 * 2 + which) * HDP + d];
+        if (which == 0) t *= scale;
+        colkv[((int64_t)b * nkb + kb) * (2 * os) + (int64_t)which * os + (int64_t)h * hd + d] = t;
+      }
+    }
+  }
 #pragma unroll
   for (int kt = 0; kt < KT; kt++) {
     if (key_ok[kt]) {
@@ -638,14 +963,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 //   delta[q] = sum_d dO[q,d] O[q,d] (the softmax-backward row term) is computed HERE, from the dO fragments the wave holds
 //   anyway plus one read of its O rows, and written to `delta` for the dK/dV kernel, which is launched after this one:
 //   the separate delta pass (one more kernel on the critical path of every attention backward) is gone.
-template <int HDP>
+template <int HDP, bool SM>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
                                                           const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ lse2,
                                                           float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
-                                                          float sc, float scale, int nqb) {
+                                                          float sc, float scale, int nqb, float* __restrict__ colq) {
   // {K,V} x NBUF ring filled by LDS-DMA (see the forward kernel): one barrier per tile, tile t+DIST in flight
   constexpr int NBUF = HDP <= 64 ? 3 : 2, DIST = NBUF - 1, BUFB = 2 * RowTile<HDP>::BYTES, RINGB = NBUF * BUFB;
   __shared__ __attribute__((aligned(16))) char smem[RINGB];
@@ -687,6 +1012,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     lse_q[qt] = q < S ? lse2[((int64_t)b * H + h) * S + q] : INFINITY;
     dl_q[qt] = q < S ? dsum : 0.f;
     if (g == 0 && q < S) delta[((int64_t)b * H + h) * S + q] = dsum;
+    // SM: Q is the stationary operand of the score product and is used for nothing else here: it carries scale * log2 e
+    if constexpr (SM) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) qf[qt][ks] = scale_frag(qf[qt][ks], sc);
+    }
   }
   f32x4_t dqacc[2][DT];
 #pragma unroll
@@ -695,8 +1025,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int dt = 0; dt < DT; dt++) dqacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   f32x4_t ndl4[2];   // -delta[q] of this lane's query, four times: the seed of every dP accumulator block
+  f32x4_t nls4[2];   // SM: -lse2[q] four times: the seed of every score accumulator block (padded queries: -inf -> P = 0)
 #pragma unroll
-  for (int qt = 0; qt < 2; qt++) ndl4[qt] = (f32x4_t){-dl_q[qt], -dl_q[qt], -dl_q[qt], -dl_q[qt]};
+  for (int qt = 0; qt < 2; qt++) {
+    ndl4[qt] = (f32x4_t){-dl_q[qt], -dl_q[qt], -dl_q[qt], -dl_q[qt]};
+    nls4[qt] = SM ? (f32x4_t){-lse_q[qt], -lse_q[qt], -lse_q[qt], -lse_q[qt]} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
   const f32x2_t sc2 = {sc, sc};
   const int nt = (S + 63) / 64;
   const TileDma<HDP, 256> dma(tid, hd);
@@ -725,7 +1059,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int qt = 0; qt < 2; qt++)
 #pragma unroll
       for (int kt = 0; kt < 4; kt++) {
-        sacc[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        sacc[qt][kt] = nls4[qt];    // zeros, or (SM) -lse2[q]: s - lse comes out of the matrix pipe
         dpacc[qt][kt] = ndl4[qt];   // the dP accumulators start at -delta[q]: dP - delta comes out of the matrix pipe
       }
 #pragma unroll
@@ -751,7 +1085,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
           const f32x2_t sv = {sacc[qt][kt][2 * hf], sacc[qt][kt][2 * hf + 1]};
           const f32x2_t dpv = {dpacc[qt][kt][2 * hf], dpacc[qt][kt][2 * hf + 1]};
-          const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nl);
+          f32x2_t a = sv;
+          if constexpr (!SM) a = __builtin_elementwise_fma(sv, sc2, nl);
           const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
           const f32x2_t ds = e * dpv;
           sacc[qt][kt][2 * hf] = ds[0];
@@ -791,6 +1126,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       }
   }
 
+  // column partials for the qkv bias gradient (colq != nullptr): this workgroup's sum over its 128 queries of dQ (fp32, before the
+  // bf16 rounding) -> colq[b * nqb + qb][h*hd + d]; padded queries have P = 0, hence dQ = 0, and need no mask
+  if (colq != nullptr) {
+    float cq[DT][4];
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) cq[dt][r] = row16_sum(dqacc[0][dt][r] + dqacc[1][dt][r]);
+    raw_barrier();   // every wave is done with the {K, V} ring: its first 4 x HDP floats become the combine buffer
+    float* red = (float*)smem;
+    if (li == 0) {
+#pragma unroll
+      for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[w * HDP + dt * 16 + 4 * g + r] = cq[dt][r];
+    }
+    raw_barrier();
+    if (tid < hd) colq[((int64_t)b * nqb + qb) * os + (int64_t)h * hd + tid] =
+        (red[tid] + red[HDP + tid] + red[2 * HDP + tid] + red[3 * HDP + tid]) * scale;
+  }
 #pragma unroll
   for (int qt = 0; qt < 2; qt++) {
     const int q = q0 + qt * 16 + li;
@@ -837,6 +1192,23 @@ extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int
   hipLaunchKernelGGL((attn_fwd_kernel<HDPV, QTV, NB>), dim3((unsigned)nblk), dim3(8 * 64 / QTV), 0, stream,            \
                      (const bf16_t*)qkv, (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb)
   const int qt_sel = g_attn_fwd_qt;
+  if (vj_opt(VJ_OPT_ATTN_SOFTMAX) != 0 && qt_sel == 2) {   // round-4 kernels (seeded soft-max); head_dim 24: row sums on the pad column
+#define VJ_FWD_SM(HDPV, NB, PS)                                                                                       \
+  hipLaunchKernelGGL((attn_fwd_sm_kernel<HDPV, 2, NB, PS>), dim3((unsigned)nblk), dim3(256), 0, stream,                \
+                     (const bf16_t*)qkv, (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb)
+    switch (pick_hdp(hd)) {
+      case 32:
+        if (hd == 24) VJ_FWD_SM(32, 3, true);
+        else VJ_FWD_SM(32, 3, false);
+        break;
+      case 64: VJ_FWD_SM(64, 2, false); break;
+      case 96: VJ_FWD_SM(96, 2, false); break;
+      default: VJ_FWD_SM(128, 2, false);
+    }
+#undef VJ_FWD_SM
+    VJ_LAUNCH_CHECK("vj_attn_fwd");
+    return 0;
+  }
   // ring depth: 2 buffers for hd <= 64 measured equal or faster than 3 (396 vs 408 us on the ViT-L target shape) and
   // leaves 32 KB of LDS, i.e. the forward can share a CU with other work; VJ_ATTN_NBUF=3 selects the deeper ring
   static const int nb_env = [] { const char* e = getenv("VJ_ATTN_NBUF"); return e ? atoi(e) : 0; }();
@@ -862,9 +1234,47 @@ extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int
 
 extern "C" int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H) { return B * S * H * 4; }
 
+// dK/dV tiling of the current options: 16-key tiles per wave (the column-partial row count depends on it)
+static int dkdv_kt(int64_t hd) {
+  const int kt_opt = vj_opt(VJ_OPT_ATTN_DKDV_KT);
+  switch (pick_hdp(hd)) {
+    case 32: return kt_opt == 1 ? 1 : 2;
+    case 64: return kt_opt == 2 ? 2 : 1;
+    default: return 1;
+  }
+}
+// rows of the column-partial matrices vj_attn_bwd_colsum writes for one [B, S] segment: colq [rows_q][H*hd], colkv [rows_kv][2*H*hd]
+extern "C" int vj_attn_bwd_colsum_rows(int64_t B, int64_t S, int64_t hd, int64_t* rows_q, int64_t* rows_kv) {
+  VJ_CHECK_ARG(rows_q != nullptr && rows_kv != nullptr && hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_bwd_colsum_rows: bad arguments");
+  *rows_q = B * cdiv64(S, 128);
+  *rows_kv = B * cdiv64(S, 64 * dkdv_kt(hd));
+  return 0;
+}
+
+static int attn_bwd_impl(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B, int64_t S,
+                         int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, float* colq, float* colkv,
+                         hipStream_t stream);
+
 extern "C" int vj_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv,
                            int64_t B, int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes,
                            hipStream_t stream) {
+  return attn_bwd_impl(qkv, o, dout, lse2, dqkv, B, S, H, hd, scale, ws, ws_bytes, nullptr, nullptr, stream);
+}
+
+// vj_attn_bwd + the column sums of dqkv over this segment's tokens as fp32 partials (the qkv bias gradient, autograd of
+// Attention.qkv's bias, modules.py:63): colq[rows_q][H*hd] from the dQ kernel (one row per (sample, 128-query block)), colkv
+// [rows_kv][2*H*hd] from the dK/dV kernel (one row per (sample, key block)); every element of both is written.  dqkv is
+// bit-identical to vj_attn_bwd's.  Reduce with vj_reduce_segments.
+extern "C" int vj_attn_bwd_colsum(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv,
+                                  int64_t B, int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes,
+                                  float* colq, float* colkv, hipStream_t stream) {
+  VJ_CHECK_ARG(colq != nullptr && colkv != nullptr, "vj_attn_bwd_colsum: null partial buffers");
+  return attn_bwd_impl(qkv, o, dout, lse2, dqkv, B, S, H, hd, scale, ws, ws_bytes, colq, colkv, stream);
+}
+
+static int attn_bwd_impl(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B, int64_t S,
+                         int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, float* colq, float* colkv,
+                         hipStream_t stream) {
   VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_bwd: head_dim=%ld unsupported", (long)hd);
   VJ_CHECK_ARG(ws_bytes >= vj_attn_bwd_ws_bytes(B, S, H), "vj_attn_bwd: workspace too small");
   if (B * S == 0) return 0;
@@ -878,14 +1288,24 @@ extern "C" int vj_attn_bwd(const void* qkv, const void* o, const void* dout, con
 #define VJ_BWD_LAUNCH(HDPV, KTV)                                                                                   \
   do {                                                                                                             \
     const int nkb = (int)cdiv64(S, 64 * KTV);                                                                      \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HDPV>, dim3((unsigned)g2), dim3(256), 0, stream, (const bf16_t*)qkv,     \
-                       (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H,   \
-                       (int)hd, sc, scale, nqb);                                                                   \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV>), dim3((unsigned)(B * H * nkb)), dim3(256), 0, stream,      \
-                       (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B, (int)S, (int)H, \
-                       (int)hd, sc, scale, nkb);                                                                   \
+    if (sm) {                                                                                                      \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, true>), dim3((unsigned)g2), dim3(256), 0, stream,               \
+                         (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv,     \
+                         (int)B, (int)S, (int)H, (int)hd, sc, scale, nqb, colq);                                   \
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV, true>), dim3((unsigned)(B * H * nkb)), dim3(256), 0,      \
+                         stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B,       \
+                         (int)S, (int)H, (int)hd, sc, scale, nkb, colkv);                                          \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, false>), dim3((unsigned)g2), dim3(256), 0, stream,              \
+                         (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv,     \
+                         (int)B, (int)S, (int)H, (int)hd, sc, scale, nqb, colq);                                   \
+      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV, false>), dim3((unsigned)(B * H * nkb)), dim3(256), 0,     \
+                         stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B,       \
+                         (int)S, (int)H, (int)hd, sc, scale, nkb, colkv);                                          \
+    }                                                                                                              \
   } while (0)
   const int kt_opt = vj_opt(VJ_OPT_ATTN_DKDV_KT);
+  const bool sm = vj_opt(VJ_OPT_ATTN_SOFTMAX) != 0;
   switch (pick_hdp(hd)) {
     case 32: if (kt_opt == 1) VJ_BWD_LAUNCH(32, 1); else VJ_BWD_LAUNCH(32, 2); break;
     case 64: if (kt_opt == 2) VJ_BWD_LAUNCH(64, 2); else VJ_BWD_LAUNCH(64, 1); break;

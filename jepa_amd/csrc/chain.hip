@@ -266,9 +266,13 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
 #define GROUP_WS_BYTES ((int64_t)192 << 20)   // grouped weight gradients: 4 * sum N1*N2 (ViT-H: 79 MB) x split factor
 
 struct BwdLayout {
-  int64_t du[2], dx1[2], dqkv[2], dx[3], dy2, dob, dy1, delta, ln_ws, dyT[2], xT[2], tcs_ws[2], wg_ws[2], total;
-  int64_t ln_ws_bytes, tcs_ws_bytes, delta_bytes;
+  int64_t du[2], dx1[2], dqkv[2], dx[3], dy2, dob, dy1, delta, ln_ws, ln_ws2, colp_fc1, colp_q, colp_kv, dyT[2], xT[2], tcs_ws[2],
+      wg_ws[2], total;
+  int64_t ln_ws_bytes, tcs_ws_bytes, delta_bytes, colp_fc1_rows, colp_attn_rows;
 };
+int vj_layernorm_bwd_partials(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean, const float* rstd,
+                              const void* dres_bf16, void* dx_bf16, bool cs, int64_t rows, int64_t D, void* ws,
+                              int64_t ws_bytes, int64_t* nb_out, hipStream_t stream);   // norm_loss.hip
 static BwdLayout bwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
   BwdLayout L;
   int64_t off = 0;
@@ -291,6 +295,15 @@ static BwdLayout bwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
   L.delta = take(L.delta_bytes);
   L.ln_ws_bytes = vj_layernorm_bwd_ws_bytes(D);
   L.ln_ws = take(L.ln_ws_bytes);
+  // option bias_fuse: the block's column partials stay alive until ONE reduction at the end of the block's backward --
+  // a second LayerNorm partial buffer (norm2's), the fc2-dgrad epilogue's sums of du (fc1 bias) and the attention backward's
+  // sums of dqkv (qkv bias; rows bounded by M/8 + 16: enough for sequences of >= 10 tokens, shorter ones take the unfused route)
+  L.ln_ws2 = take(L.ln_ws_bytes);
+  L.colp_fc1_rows = vj_gemm_colsum_rows(M);
+  L.colp_fc1 = take(L.colp_fc1_rows * Dh * 4);
+  L.colp_attn_rows = M / 8 + 16;
+  L.colp_q = take(L.colp_attn_rows * D * 4);
+  L.colp_kv = take(L.colp_attn_rows * 2 * D * 4);
   L.tcs_ws_bytes = vj_transpose_colsum_ws_bytes(M, nmax);
   if (vj_colsum_ws_bytes(nmax) > L.tcs_ws_bytes) L.tcs_ws_bytes = vj_colsum_ws_bytes(nmax);
   for (int w = 0; w < 1; w++) {   // scratch of the weight-gradient stream
@@ -416,39 +429,117 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     // dx2 of every block but the last is the dx of block li+1's norm1 backward, which also produced its column sums
     const bool fuse_cs = sc.tn != 0;   // (the NT route folds the bias gradient into its dY transpose instead)
     const bool grouped = sc.tn != 0 && vj_opt(VJ_OPT_WGRAD_GROUP) != 0 && D % 8 == 0 && Dh % 8 == 0;
-    const WgradItem items[4] = {{dx2, w + F.g, &b.fc2, fuse_cs && li + 1 < n_blocks},
+    // (flags bit 1: the caller's final-norm backward already wrote the LAST block's fc2 bias gradient, the column sums of dout)
+    const bool fc2_done = fuse_cs && (li + 1 < n_blocks || (flags & 2) != 0);
+    const WgradItem items[4] = {{dx2, w + F.g, &b.fc2, fc2_done},
                                 {du, w + F.y2, &b.fc1, false},
                                 {dx1, w + F.o, &b.proj, fuse_cs},
                                 {dqkv, w + F.y1, &b.qkv, false}};
-    if (!grouped) CH(wgrad(sc, dx2, w + F.g, b.fc2, fuse_cs && li + 1 < n_blocks));
-    CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream, g_dgrad_flags));
+    if (!grouped) CH(wgrad(sc, dx2, w + F.g, b.fc2, fc2_done));
+    // option bias_fuse (with the transpose-free route): every column partial the block produces -- both LayerNorm backwards',
+    // the fc2-dgrad epilogue's sums of du (= fc1's bias gradient) and the attention backward's sums of dqkv (= qkv's) -- is
+    // reduced by ONE vj_reduce_segments launch at the end of the block instead of two reductions + two column-sum passes over
+    // du / dqkv + their two reductions (6 launches, 143 MB re-read per ViT-L context block)
+    const bool bfuse = fuse_cs && vj_opt(VJ_OPT_BIAS_FUSE) != 0;
+    vj_reduce_seg_t rsegs[12];
+    int n_rsegs = 0;
+    int fc1_fused = 0;
+    if (bfuse && b.fc1.gb != nullptr) {
+      ProfScope ps(stream, 0, 2.0 * M * Dh * D, M, Dh, D, 2);
+      CH(vj_gemm_bf16_nt_dgelu_colsum(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, w + F.u, Dh, (float*)(tmp + L.colp_fc1),
+                                      L.colp_fc1_rows, g_dgrad_flags, &fc1_fused, stream));
+      if (fc1_fused) rsegs[n_rsegs++] = vj_reduce_seg_t{(const float*)(tmp + L.colp_fc1), b.fc1.gb, L.colp_fc1_rows, Dh, Dh};
+    } else {
+      CH(gemm(dx2, D, b.fc2.wT, b.fc2.ldwT, du, Dh, M, Dh, D, nullptr, nullptr, 0, w + F.u, nullptr, Dh, 2, stream, g_dgrad_flags));
+    }
     // fc1
-    if (!grouped) CH(wgrad(sc, du, w + F.y2, b.fc1));
+    if (!grouped) CH(wgrad(sc, du, w + F.y2, b.fc1, fc1_fused != 0));
     CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     // dx1 is the dY of proj: its bias gradient = column sums of dx1, produced by this pass
-    CH(vj_layernorm_bwd_colsum(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
-                               dx1, b.norm2.gg, b.norm2.gb, fuse_cs ? b.proj.gb : nullptr, alpha, beta_acc, M, D,
-                               tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    if (bfuse) {
+      int64_t nb2 = 0;
+      const bool cs2 = b.proj.gb != nullptr;
+      CH(vj_layernorm_bwd_partials(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
+                                   dx1, cs2, M, D, tmp + L.ln_ws2, L.ln_ws_bytes, &nb2, stream));
+      const int64_t st2 = (cs2 ? 3 : 2) * D;
+      const float* p2 = (const float*)(tmp + L.ln_ws2);
+      rsegs[n_rsegs++] = vj_reduce_seg_t{p2, b.norm2.gg, nb2, D, st2};
+      rsegs[n_rsegs++] = vj_reduce_seg_t{p2 + D, b.norm2.gb, nb2, D, st2};
+      if (cs2) rsegs[n_rsegs++] = vj_reduce_seg_t{p2 + 2 * D, b.proj.gb, nb2, D, st2};
+    } else {
+      CH(vj_layernorm_bwd_colsum(tmp + L.dy2, w + F.x1, b.norm2.g, (const float*)(w + F.mean2), (const float*)(w + F.rstd2), dx2,
+                                 dx1, b.norm2.gg, b.norm2.gb, fuse_cs ? b.proj.gb : nullptr, alpha, beta_acc, M, D,
+                                 tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    }
     // proj
     if (!grouped) CH(wgrad(sc, dx1, w + F.o, b.proj, fuse_cs));
     CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
+    // qkv bias: column partials from the attention backward kernels, when every segment's partial rows fit the workspace
+    int64_t rows_q = 0, rows_kv = 0;
+    bool qkv_fused = bfuse && b.qkv.gb != nullptr;
+    if (qkv_fused) {
+      for (int64_t s = 0; s < n_segs; s++) {
+        int64_t rq = 0, rkv = 0;
+        if (segs[s].B * segs[s].S == 0) continue;
+        CH(vj_attn_bwd_colsum_rows(segs[s].B, segs[s].S, hd, &rq, &rkv));
+        rows_q += rq;
+        rows_kv += rkv;
+      }
+      if (rows_q > L.colp_attn_rows || rows_kv > L.colp_attn_rows) qkv_fused = false;
+    }
+    int64_t off_q = 0, off_kv = 0;
     for (int64_t s = 0; s < n_segs; s++) {
       const vj_seg_t& sg = segs[s];
       if (sg.B * sg.S == 0) continue;
       ProfScope ps(stream, 2, 8.0 * sg.B * heads * sg.S * sg.S * hd, sg.B, sg.S, heads, (int)hd);
-      CH(vj_attn_bwd(w + F.qkv + sg.row0 * 3 * D * 2, w + F.o + sg.row0 * D * 2, tmp + L.dob + sg.row0 * D * 2,
-                     (const float*)(w + F.lse) + heads * sg.row0, dqkv + sg.row0 * 3 * D * 2, sg.B, sg.S, heads, hd, scale,
-                     tmp + L.delta, L.delta_bytes, stream));
+      if (qkv_fused) {
+        int64_t rq = 0, rkv = 0;
+        CH(vj_attn_bwd_colsum_rows(sg.B, sg.S, hd, &rq, &rkv));
+        CH(vj_attn_bwd_colsum(w + F.qkv + sg.row0 * 3 * D * 2, w + F.o + sg.row0 * D * 2, tmp + L.dob + sg.row0 * D * 2,
+                              (const float*)(w + F.lse) + heads * sg.row0, dqkv + sg.row0 * 3 * D * 2, sg.B, sg.S, heads, hd,
+                              scale, tmp + L.delta, L.delta_bytes, (float*)(tmp + L.colp_q) + off_q * D,
+                              (float*)(tmp + L.colp_kv) + off_kv * 2 * D, stream));
+        off_q += rq;
+        off_kv += rkv;
+      } else {
+        CH(vj_attn_bwd(w + F.qkv + sg.row0 * 3 * D * 2, w + F.o + sg.row0 * D * 2, tmp + L.dob + sg.row0 * D * 2,
+                       (const float*)(w + F.lse) + heads * sg.row0, dqkv + sg.row0 * 3 * D * 2, sg.B, sg.S, heads, hd, scale,
+                       tmp + L.delta, L.delta_bytes, stream));
+      }
+    }
+    if (qkv_fused) {
+      rsegs[n_rsegs++] = vj_reduce_seg_t{(const float*)(tmp + L.colp_q), b.qkv.gb, rows_q, D, D};
+      rsegs[n_rsegs++] = vj_reduce_seg_t{(const float*)(tmp + L.colp_kv), b.qkv.gb + D, rows_kv, 2 * D, 2 * D};
     }
     // qkv
-    if (grouped) CH(wgrad_group(sc, items, 4));
-    else CH(wgrad(sc, dqkv, w + F.y1, b.qkv));
+    if (grouped) {
+      WgradItem git[4] = {items[0], items[1], items[2], items[3]};
+      git[1].bias_done = fc1_fused != 0;
+      git[3].bias_done = qkv_fused;
+      CH(wgrad_group(sc, git, 4));
+    } else {
+      CH(wgrad(sc, dqkv, w + F.y1, b.qkv, qkv_fused));
+    }
     CH(gemm(dqkv, 3 * D, b.qkv.wT, b.qkv.ldwT, tmp + L.dy1, D, M, D, 3 * D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0,
             stream, g_dgrad_flags));
     // dx is the dY of the previous block's fc2 (its dx2): that bias gradient comes out of this pass
-    CH(vj_layernorm_bwd_colsum(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
-                               b.norm1.gg, b.norm1.gb, (fuse_cs && li > 0) ? blocks[li - 1].fc2.gb : nullptr, alpha, beta_acc,
-                               M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    if (bfuse) {
+      int64_t nb1 = 0;
+      float* prev_gb = li > 0 ? blocks[li - 1].fc2.gb : nullptr;
+      const bool cs1 = prev_gb != nullptr;
+      CH(vj_layernorm_bwd_partials(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
+                                   cs1, M, D, tmp + L.ln_ws, L.ln_ws_bytes, &nb1, stream));
+      const int64_t st1 = (cs1 ? 3 : 2) * D;
+      const float* p1 = (const float*)(tmp + L.ln_ws);
+      rsegs[n_rsegs++] = vj_reduce_seg_t{p1, b.norm1.gg, nb1, D, st1};
+      rsegs[n_rsegs++] = vj_reduce_seg_t{p1 + D, b.norm1.gb, nb1, D, st1};
+      if (cs1) rsegs[n_rsegs++] = vj_reduce_seg_t{p1 + 2 * D, prev_gb, nb1, D, st1};
+      CH(vj_reduce_segments(rsegs, n_rsegs, alpha, beta_acc, stream));   // the block's ONE reduction launch
+    } else {
+      CH(vj_layernorm_bwd_colsum(tmp + L.dy1, x, b.norm1.g, (const float*)(w + F.mean1), (const float*)(w + F.rstd1), dx1, dx,
+                                 b.norm1.gg, b.norm1.gb, (fuse_cs && li > 0) ? blocks[li - 1].fc2.gb : nullptr, alpha, beta_acc,
+                                 M, D, tmp + L.ln_ws, L.ln_ws_bytes, stream));
+    }
     if (sc.side != sc.main) {
       hipEvent_t e = next_event();
       HIPCH(hipEventRecord(e, sc.side), "vj_blocks_bwd");

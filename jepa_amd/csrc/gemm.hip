@@ -346,6 +346,7 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.tiles_m = a.tiles_n = 0; a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
   a.dbg = vj_opt(VJ_OPT_GEMM_DBG);
   a.zero_row = nullptr;
+  a.colpart = nullptr;
   switch (epilogue) {
     case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, nullptr, 0, stream);
     case EPI_GELU: return dispatch_gemm<EPI_GELU>(a, flags, nullptr, 0, stream);
@@ -360,6 +361,45 @@ extern "C" int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_
                                float beta, int flags, hipStream_t stream) {
   return gemm_entry(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, aux_in, aux_out, ldaux, epilogue, alpha, beta,
                     flags, nullptr, 0, stream);
+}
+
+// fc2 dgrad with the bias gradient of fc1 fused: C = (A B^T) * aux_in (EPI_DGELU) and, when the persistent 256x256 kernel
+// takes the problem, colpart[2 * cdiv(M,256)][N] = per-(row tile, wave row) fp32 column sums of C before the bf16 rounding
+// (*fused = 1; reduce them with vj_reduce_segments).  Otherwise the plain GEMM runs and *fused = 0 (the caller sums C itself).
+// C is bit-identical to vj_gemm_bf16_nt's either way.  Replaces: autograd of Mlp.fc1's bias (modules.py:31-34).
+extern "C" int64_t vj_gemm_colsum_rows(int64_t M) { return 2 * cdiv64(M, 256); }
+
+extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                            int64_t M, int64_t N, int64_t K, const void* aux_in, int64_t ldaux,
+                                            float* colpart, int64_t colpart_rows, int flags, int* fused,
+                                            hipStream_t stream) {
+  VJ_CHECK_ARG(fused != nullptr, "vj_gemm_bf16_nt_dgelu_colsum: null `fused`");
+  *fused = 0;
+  const int64_t t256 = cdiv64(M, 256) * cdiv64(N, 256);
+  if (colpart != nullptr && flags == 0 && M > 0 && N > 0 && K > 0 && K % 64 == 0 && t256 >= 90 && vj_opt(VJ_OPT_GEMM_4W) == 0 &&
+      vj_opt(VJ_OPT_GEMM_PERSIST) != 0 && vj_opt(VJ_OPT_GEMM_DBG) == 0 && aux_in != nullptr && lda % 8 == 0 && ldb % 8 == 0 &&
+      lda >= K && ldb >= K && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ldc % 4 == 0 && ldc >= N &&
+      ldaux % 4 == 0 && N % 4 == 0 && (uintptr_t)C % 8 == 0) {
+    // the same kernel the automatic selection of vj_gemm_bf16_nt picks for this shape (>= 90 tiles of 256 x 256, K % 64 == 0)
+    VJ_CHECK_ARG(colpart_rows >= vj_gemm_colsum_rows(M), "vj_gemm_bf16_nt_dgelu_colsum: colpart has %ld rows, needs %ld",
+                 (long)colpart_rows, (long)vj_gemm_colsum_rows(M));
+    GemmArgs a;
+    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.bias = nullptr; a.res = nullptr;
+    a.aux_in = (const bf16_t*)aux_in; a.aux_out = nullptr;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = 0; a.ldaux = ldaux;
+    a.alpha = 1.0f; a.beta = 0.0f;
+    a.tiles_m = a.tiles_n = 0; a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
+    a.dbg = 0;
+    a.zero_row = nullptr;
+    a.colpart = colpart;
+    const int rc = vj_gemm_launch_8phase_persist(a, EPI_DGELU, stream);
+    if (rc != -100) {
+      *fused = (rc == 0);
+      return rc;
+    }
+  }
+  return gemm_entry(A, lda, B, ldb, C, ldc, M, N, K, nullptr, nullptr, 0, aux_in, nullptr, ldaux, EPI_DGELU, 1.0f, 0.0f, flags,
+                    nullptr, 0, stream);
 }
 
 // wgrad form: C (fp32) = alpha * A B^T + beta * C with the long K (= tokens) dimension split across workgroups

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
   const bool late_group = wave_u >= 4;
 
   GemmArgs p;
+  p.colpart = nullptr;
   int logical_all;
   if constexpr (GROUPED) {
     const int l = xcd_logical(blockIdx.x, ga.unit_end[ga.n - 1]);
@@ -404,6 +405,7 @@ static int tn_check(const char* who, const void* dY, int64_t ldy, const void* X,
 static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw, int64_t T,
                         int64_t N1, int64_t N2, float alpha, float beta) {
   GemmArgs b;
+  b.colpart = nullptr;
   b.A = (const bf16_t*)dY; b.B = (const bf16_t*)X; b.C = dW; b.bias = nullptr; b.res = nullptr; b.aux_in = nullptr;
   b.aux_out = nullptr;
   b.M = N1; b.N = N2; b.K = T; b.lda = ldy; b.ldb = ldx; b.ldc = ldw; b.ldr = 0; b.ldaux = 0;

@@ -78,8 +78,8 @@ __device__ __forceinline__ void pp_make_bases(PpBases& pb, const char* a0, const
 }
 
 // logical tile index -> shifted tile origin (always a full 256 x 256 tile inside the matrix)
-__device__ __forceinline__ void pp_tile_origin(const GemmArgs& p, int logical, int64_t& m0, int64_t& n0) {
-  int tm, tn;
+__device__ __forceinline__ void pp_tile_origin(const GemmArgs& p, int logical, int64_t& m0, int64_t& n0, int& tm) {
+  int tn;
   tile_of(logical, p.tiles_m, p.tiles_n, tm, tn);
   m0 = (int64_t)tm * 256;
   n0 = (int64_t)tn * 256;
@@ -287,7 +287,8 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
 
   // ---- first tile: parts -1 .. 5 in flight, all landed before anybody reads
   int64_t m0, n0;
-  pp_tile_origin(p, band0 + pos, m0, n0);
+  int tm_cur;                                  // un-shifted row-tile index of the current tile (column-sum slot / row ownership)
+  pp_tile_origin(p, band0 + pos, m0, n0, tm_cur);
   pp_make_bases(cur, (const char*)(p.A + m0 * p.lda), (const char*)(p.B + n0 * p.ldb), lda2, ldb2);
   int h = 0;                                   // ring half of the current tile's K-tile 0 (toggles every K-tile, across tiles)
   issue(K_A0{}, cur, 0, 1);                    // part -1: A0(0) -> half h^1, slot 3
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
   for (int ti = 0; ti < my_tiles; ti++) {
     const bool has_next = ti + 1 < my_tiles;   // workgroup-uniform
     int64_t m0n, n0n;
-    pp_tile_origin(p, band0 + pos + (has_next ? ti + 1 : ti) * wgs_x, m0n, n0n);
+    int tm_next;
+    pp_tile_origin(p, band0 + pos + (has_next ? ti + 1 : ti) * wgs_x, m0n, n0n, tm_next);
     a0n = (const char*)(p.A + m0n * p.lda);
     b0n = (const char*)(p.B + n0n * p.ldb);
 #pragma unroll
@@ -341,11 +343,14 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
       const int efrow = elane & 15, efg = elane >> 4;
       pp_wait<0>();
+      // (column sums, EPI_DGELU with p.colpart: a shifted edge tile owns only its rows >= tm * 256; slot = 2 tm + wave row)
       (void)gemm_epilogue_try_staged<EPI, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
-                                             smem + PP_RING + wave_u * PP_STAGE_PER_WAVE);
+                                             smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
+                                             tm_cur * 2 + wm);
     }
     m0 = m0n;
     n0 = n0n;
+    tm_cur = tm_next;
     pp_make_bases(cur, a0n, b0n, lda2, ldb2);
   }
 }
@@ -374,6 +379,7 @@ static bool persist_ok(const GemmArgs& a, int ncu) {
     return q0 < c1 && c0 < q1;
   };
   if (overlaps(a.res, a.ldr) || overlaps(a.aux_in, a.ldaux) || overlaps(a.A, a.lda)) return false;
+  if (a.colpart != nullptr && (EPI != EPI_DGELU || ((uintptr_t)a.colpart & 15) != 0)) return false;
   return true;
 }
 

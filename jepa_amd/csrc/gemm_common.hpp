@@ -20,6 +20,8 @@ struct GemmArgs {
   float* ws;
   const bf16_t* zero_row;   // 128 bf16 zeros: source of token rows beyond T in the TN weight-gradient kernel (gemm8_tn.hip)
   int dbg;             // diagnostics (env VJ_GEMM_DBG, tools/gemm_ksweep.py): bit0 = drop the epilogue, bit1 = direct (unstaged) stores
+  float* colpart;      // EPI_DGELU on the persistent kernel, nullable: fp32 column-sum partials of the OUTPUT, [2 * tiles_m][N]
+                       // (row slot = 2 * row tile + wave row): the bias gradient of the Linear whose dY this GEMM produces
 };
 
 
@@ -156,9 +158,14 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 // swizzled by (row >> 1) & 7: conflict-free reads, 2-way writes that hide under the ds_write data transfer) and reads
 // it back row-major: one ds_read_b128 + one 16-byte store per lane, eight complete 128-byte lines per instruction.
 // The arithmetic (bias, residual, GELU) stays in the MFMA layout and is identical to gemm_epilogue_impl.
-template <int EPI, bool HAS_OPT, bool EDGE, int IPP>
+// CSUM (EPI_DGELU only): the wave also sums its 128 x 64 output tile over the rows (fp32 values before the bf16 rounding;
+// rows below `row_lo` -- the part of a SHIFTED edge tile that belongs to its neighbour -- are left out) and writes the 64
+// column sums to p.colpart[slot][n_base ..]: du = dY of fc1 is produced here, so fc1's bias gradient costs 64 packed FMAs + 64
+// DPP adds per wave tile instead of a second pass over du (colsum_bf16_kernel: 84 MB per ViT-L context block).
+template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
-                                                     int64_t n_base, int frow, int fg, int lane, char* stage) {
+                                                     int64_t n_base, int frow, int fg, int lane, char* stage,
+                                                     int64_t row_lo = 0, int slot = 0) {
   // IPP = 16-row blocks per pass: 8 -> the whole wave tile in one 16 KB pass (stage = 16 KB per wave, the dead operand
   // ring of the one-tile-per-workgroup kernel); 2 -> four 4 KB passes (persistent kernel: the ring already holds the
   // next tile's first parts, the staging area is a separate 32 KB).
@@ -222,6 +229,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
 #pragma unroll
     for (int j = 0; j < FN; j++) dst[j] = *(const u32x2_t*)(base + ncl[j]);
   };
+  static_assert(!CSUM || (EPI == EPI_DGELU && !EDGE), "column sums: the fc2-dgrad epilogue of the persistent kernel");
+  f32x2_t cs01[CSUM ? FN : 1], cs23[CSUM ? FN : 1];
+  if constexpr (CSUM) {
+#pragma unroll
+    for (int j = 0; j < FN; j++) cs01[j] = cs23[j] = (f32x2_t){0.f, 0.f};
+  }
+  const int row_first = (int)(row_lo - m_base) - frow;   // CSUM: block i of this lane counts iff i * 16 >= row_first
   if constexpr (HAS_OPND) load_row(0, opnd[0]);
 #pragma unroll
   for (int ps = 0; ps < FM / RPP; ps++) {
@@ -230,6 +244,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       const int i = ps * RPP + ii;
       if constexpr (HAS_OPND) {
         if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
+      }
+      f32x2_t mk2 = {1.f, 1.f};
+      if constexpr (CSUM) {
+        const float mk = (i * 16 >= row_first) ? 1.f : 0.f;
+        mk2 = (f32x2_t){mk, mk};
       }
 #pragma unroll
       for (int j = 0; j < FN; j++) {
@@ -257,6 +276,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
           const u32x2_t u = opnd[i & 1][j];   // saved gelu'(u)
           v01 *= (f32x2_t){bf_lo(u[0]), bf_hi(u[0])};
           v23 *= (f32x2_t){bf_lo(u[1]), bf_hi(u[1])};
+          if constexpr (CSUM) {
+            cs01[j] = __builtin_elementwise_fma(v01, mk2, cs01[j]);
+            cs23[j] = __builtin_elementwise_fma(v23, mk2, cs23[j]);
+          }
         } else if constexpr (HAS_OPT) {
           const u32x2_t r2 = opnd[i & 1][j];
           v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
@@ -270,13 +293,32 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     if constexpr (TWO_OUT) flush(p.aux_out, p.ldaux, ps * RPP * 16, 0);
     flush((bf16_t*)p.C, p.ldc, ps * RPP * 16, TWO_OUT ? RPP : 0);
   }
+  if constexpr (CSUM) {
+    // sum over the 16 rows (lanes frow = 0..15 of each 16-lane DPP row hold the same columns): rotate-and-add, fixed order
+    float cv[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      cv[j][0] = cs01[j][0];
+      cv[j][1] = cs01[j][1];
+      cv[j][2] = cs23[j][0];
+      cv[j][3] = cs23[j][1];
+#pragma unroll
+      for (int c = 0; c < 4; c++) cv[j][c] = row16_sum(cv[j][c]);
+    }
+    if (frow == 0) {
+      float* cp = p.colpart + (int64_t)slot * p.N + n_base + fg * 4;
+#pragma unroll
+      for (int j = 0; j < FN; j++) *(float4*)(cp + j * 16) = make_float4(cv[j][0], cv[j][1], cv[j][2], cv[j][3]);
+    }
+  }
 }
 
 // staged variant selector for the 8-phase kernel (wave tile 128 x 64); falls back to the direct form when the 16-byte
 // row-major stores cannot be used (N, ldc or the base pointers not 8-element aligned) and for fp32 outputs
 template <int EPI, int IPP = 8>
 __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
-                                                         int64_t n_base, int frow, int fg, int lane, char* stage) {
+                                                         int64_t n_base, int frow, int fg, int lane, char* stage,
+                                                         int64_t row_lo = 0, int slot = 0) {
   if constexpr (EPI == EPI_F32) {
     return false;
   } else {
@@ -288,6 +330,12 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     else if constexpr (EPI == EPI_BF16) opt = p.res != nullptr;
     else opt = true;
     const bool edge = __builtin_amdgcn_readfirstlane((m_base + 128 > p.M) || (n_base + 64 > p.N));
+    if constexpr (EPI == EPI_DGELU && IPP == 2) {   // persistent kernel (every tile interior): optional fused column sums
+      if (p.colpart != nullptr && !edge) {
+        gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot);
+        return true;
+      }
+    }
     if (opt) {
       if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
       else gemm_epilogue_staged<EPI, true, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);

@@ -228,13 +228,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 
 extern "C" int64_t vj_layernorm_bwd_ws_bytes(int64_t D) { return (int64_t)LN_BWD_MAX_BLOCKS * 3 * D * 4; }
 
-// dgamma/dbeta (and dxsum, nullable: column sums of dx) : out = alpha * sum + beta_acc * out   (beta_acc = 1 accumulates)
-extern "C" int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
-                                       const float* rstd, const void* dres_bf16, void* dx_bf16, float* dgamma,
-                                       float* dbeta, float* dxsum, float alpha, float beta_acc, int64_t rows, int64_t D,
-                                       void* ws, int64_t ws_bytes, hipStream_t stream) {
+// The backward kernel alone: dx is complete, the column partials part[nb][nseg * D] (nseg = 3 with `cs`: dgamma | dbeta |
+// column sums of dx; else 2) are left in `ws` for the caller to reduce (the block chain reduces everything a block produced
+// in ONE launch, chain.hip).  *nb_out = number of partial rows.
+int vj_layernorm_bwd_partials(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean, const float* rstd,
+                              const void* dres_bf16, void* dx_bf16, bool cs, int64_t rows, int64_t D, void* ws,
+                              int64_t ws_bytes, int64_t* nb_out, hipStream_t stream) {
   VJ_CHECK_ARG(D % 8 == 0 && D <= 512 * LN_MAX_CHUNKS, "vj_layernorm_bwd: D=%ld unsupported", (long)D);
   VJ_CHECK_ARG(ws_bytes >= vj_layernorm_bwd_ws_bytes(D), "vj_layernorm_bwd: workspace too small");
+  *nb_out = 0;
   if (rows == 0) return 0;
   int64_t nb = cdiv64(rows, 16);  // >= 16 rows per workgroup so the column partials amortise
   if (nb > LN_BWD_MAX_BLOCKS) nb = LN_BWD_MAX_BLOCKS;
@@ -243,7 +245,7 @@ extern "C" int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, 
   hipLaunchKernelGGL((layernorm_bwd_kernel<NCHV, CSV>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16, \
                      (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws,    \
                      rows, (int)D)
-  if (dxsum != nullptr) {
+  if (cs) {
     if (D <= 512) VJ_LNB(1, true);
     else if (D <= 1024) VJ_LNB(2, true);
     else if (D <= 1536) VJ_LNB(3, true);
@@ -256,6 +258,20 @@ extern "C" int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, 
   }
 #undef VJ_LNB
   VJ_LAUNCH_CHECK("vj_layernorm_bwd");
+  *nb_out = nb;
+  return 0;
+}
+
+// dgamma/dbeta (and dxsum, nullable: column sums of dx) : out = alpha * sum + beta_acc * out   (beta_acc = 1 accumulates)
+extern "C" int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean,
+                                       const float* rstd, const void* dres_bf16, void* dx_bf16, float* dgamma,
+                                       float* dbeta, float* dxsum, float alpha, float beta_acc, int64_t rows, int64_t D,
+                                       void* ws, int64_t ws_bytes, hipStream_t stream) {
+  int64_t nb = 0;
+  if (int rc = vj_layernorm_bwd_partials(dy_bf16, x_bf16, gamma, mean, rstd, dres_bf16, dx_bf16, dxsum != nullptr, rows, D, ws,
+                                         ws_bytes, &nb, stream))
+    return rc;
+  if (nb == 0) return 0;
   float* outs[3] = {dgamma, dbeta, dxsum};
   return vj_reduce_partials_multi((const float*)ws, outs, dxsum != nullptr ? 3 : 2, nb, D, alpha, beta_acc, stream);   // ONE launch
 }

@@ -8,6 +8,7 @@
 //   x += pos_embed                   src/models/vision_transformer.py:172-174
 //   predictor token assembly         src/models/predictor.py:194-221
 #include "common.hpp"
+#include "../../include/vjepa_hip.h"
 
 // ---------------------------------------------------------------------------------------------
 // gather_rows: dst[b,k,:] = src[b*src_bstride + idx[b,k], :]   (payload moved verbatim -> bit exact)
@@ -417,6 +418,71 @@ int vj_reduce_partials_multi(const float* part, float* const* outs, int nseg, in
 extern "C" int vj_reduce_partials(const float* part, float* out, int64_t P, int64_t N, float alpha, float beta,
                                   hipStream_t stream) {
   return vj_reduce_partials_strided(part, out, P, N, N, alpha, beta, stream);
+}
+
+// Several independent partial reductions in ONE launch: segment s computes out_s[n] = alpha * sum_p part_s[p * stride_s + n]
+// (+ beta * out_s[n]), n < N_s.  Same per-column arithmetic and summation order as reduce_partials_kernel (8 partial lanes,
+// fixed-order combine), so a reduction gives the same bits whether it runs alone or as a segment here.  The backward of a
+// transformer block ends with one such launch (LayerNorm dgamma | dbeta | proj / fc2 bias sums of both norms + the qkv and fc1
+// bias partials of the producing kernels) instead of six reduction / column-sum launches.
+#define VJ_REDUCE_MAX_SEGS 16
+struct ReduceSegs {
+  const float* part[VJ_REDUCE_MAX_SEGS];
+  float* out[VJ_REDUCE_MAX_SEGS];
+  int64_t P[VJ_REDUCE_MAX_SEGS], N[VJ_REDUCE_MAX_SEGS], stride[VJ_REDUCE_MAX_SEGS];
+  int blk_end[VJ_REDUCE_MAX_SEGS];   // exclusive prefix sums of the segments' workgroup counts (cdiv(N, 64) each)
+  int n;
+};
+__global__ __launch_bounds__(512) void reduce_segments_kernel(ReduceSegs rs, float alpha, float beta) {
+  __shared__ float red[8][64];
+  int sg = 0;
+  while (sg + 1 < rs.n && (int)blockIdx.x >= rs.blk_end[sg]) sg++;      // workgroup-uniform
+  const int blk0 = sg == 0 ? 0 : rs.blk_end[sg - 1];
+  const float* part = rs.part[sg];
+  const int64_t P = rs.P[sg], N = rs.N[sg], stride = rs.stride[sg];
+  const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int64_t n = (int64_t)((int)blockIdx.x - blk0) * 64 + c;
+  float s = 0.f;
+  if (n < N) {
+#pragma unroll 8
+    for (int64_t p = pl; p < P; p += 8) s += part[p * stride + n];
+  }
+  red[pl][c] = s;
+  __syncthreads();
+  if (pl == 0 && n < N) {
+    float t = red[0][c];
+#pragma unroll
+    for (int i = 1; i < 8; i++) t += red[i][c];
+    t *= alpha;
+    float* o = rs.out[sg] + n;
+    if (beta != 0.f) t += beta * *o;
+    *o = t;
+  }
+}
+
+extern "C" int vj_reduce_segments(const vj_reduce_seg_t* segs, int64_t n_segs, float alpha, float beta, hipStream_t stream) {
+  VJ_CHECK_ARG(segs != nullptr && n_segs >= 0 && n_segs <= VJ_REDUCE_MAX_SEGS, "vj_reduce_segments: 0..%d segments", VJ_REDUCE_MAX_SEGS);
+  ReduceSegs rs;
+  int nb = 0, k = 0;
+  for (int64_t i = 0; i < n_segs; i++) {
+    const vj_reduce_seg_t& sg = segs[i];
+    VJ_CHECK_ARG(sg.P >= 0 && sg.N >= 0 && sg.stride >= sg.N, "vj_reduce_segments: segment %ld has bad dims", (long)i);
+    if (sg.N == 0) continue;
+    VJ_CHECK_ARG(sg.out != nullptr && (sg.part != nullptr || sg.P == 0), "vj_reduce_segments: segment %ld has null pointers", (long)i);
+    rs.part[k] = sg.part;
+    rs.out[k] = sg.out;
+    rs.P[k] = sg.P;
+    rs.N[k] = sg.N;
+    rs.stride[k] = sg.stride;
+    nb += (int)cdiv64(sg.N, 64);
+    rs.blk_end[k] = nb;
+    k++;
+  }
+  if (k == 0) return 0;
+  rs.n = k;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3((unsigned)nb), dim3(512), 0, stream, rs, alpha, beta);
+  VJ_LAUNCH_CHECK("vj_reduce_segments");
+  return 0;
 }
 
 extern "C" int64_t vj_colsum_ws_bytes(int64_t N) { return (int64_t)VJ_COLSUM_PARTS * N * 4; }

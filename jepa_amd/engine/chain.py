@@ -105,9 +105,12 @@ def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None, gemm_flags=0)
     return out, (TrunkCtx(x, ws, M, D, segs, sa) if save else None)
 
 
-def blocks_backward(dout, ctx, views, alpha, side_stream=None, on_layer_done=None, beta_acc=0.0, tag="bwd_tmp"):
+def blocks_backward(dout, ctx, views, alpha, side_stream=None, on_layer_done=None, beta_acc=0.0, tag="bwd_tmp",
+                    last_fc2_bias_done=False):
     """dout [M, D] bf16 (gradient of the trunk output) -> dx [M, D] bf16; parameter gradients go into the arena views.
-    side_stream: raw hipStream_t (int) for the weight gradients or None; on_layer_done(layer) is called per block."""
+    side_stream: raw hipStream_t (int) for the weight gradients or None; on_layer_done(layer) is called per block.
+    last_fc2_bias_done: the caller's LayerNorm backward that produced `dout` already wrote the last block's fc2 bias gradient
+    (the column sums of dout) -- flags bit 1 of vj_blocks_bwd."""
     lib = load_library()
     M, D = ctx.M, ctx.D
     arr = _blocks_of(views)
@@ -129,7 +132,7 @@ def blocks_backward(dout, ctx, views, alpha, side_stream=None, on_layer_done=Non
         dout.record_stream(torch.cuda.ExternalStream(side_stream, device=dout.device))
     check(lib.vj_blocks_bwd(arr, n, ctx.x_in.data_ptr(), dout.data_ptr(), dx.data_ptr(), M, D, views.heads, ctx.seg_arr,
                             len(ctx.segs), alpha, beta_acc, ctx.ws.data_ptr(), ctx.ws.numel(), tmp.data_ptr(),
-                            tmp.numel(), 0, torch.cuda.current_stream().cuda_stream, side_stream, cb,
+                            tmp.numel(), 2 if last_fc2_bias_done else 0, torch.cuda.current_stream().cuda_stream, side_stream, cb,
                             None), "vj_blocks_bwd")
     if errs:
         raise errs[0]

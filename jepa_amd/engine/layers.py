@@ -249,16 +249,21 @@ def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_don
     """dout [M, D] bf16: gradient of the encoder output rows.  Pixels need no gradient.  Parameter gradients are written
     as alpha * grad + beta * old (beta = 1 accumulates micro-batches)."""
     tok, saved_blocks, xl, mean, rstd = saved
-    dx = ops.layernorm_bwd(dout, xl, ew.norm.g, mean, rstd, ew.norm.gg, ew.norm.gb, alpha=alpha, accumulate=beta != 0.0)
+    # dx of the final norm's backward is the dY of the last block's fc2: with the transpose-free route its bias gradient (the
+    # column sums of dx) comes out of this pass like every other block's (round 4: no stand-alone column sum left in a trunk)
+    last_gb = ew.blocks[-1].fc2.gb if _tn_ok(8, 8) else None
+    dx = ops.layernorm_bwd(dout, xl, ew.norm.g, mean, rstd, ew.norm.gg, ew.norm.gb, alpha=alpha, accumulate=beta != 0.0,
+                           dxsum=last_gb)
     if isinstance(saved_blocks, chain.TrunkCtx):
         side = side_stream(dout.device)
         dx = chain.blocks_backward(dx, saved_blocks, ew, alpha, side.stream.cuda_stream if side.enabled else None,
                                    (lambda li: on_layer_done("enc", li)) if on_layer_done is not None else None,
-                                   beta_acc=beta, tag=ws_tag)
+                                   beta_acc=beta, tag=ws_tag, last_fc2_bias_done=last_gb is not None)
     else:
         nb = len(ew.blocks)
         for li in range(nb - 1, -1, -1):
-            dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha, beta, fc2_bias_done=li + 1 < nb,
+            dx = block_backward(dx, saved_blocks[li], ew.blocks[li], segs, ew.heads, alpha, beta,
+                                fc2_bias_done=li + 1 < nb or last_gb is not None,
                                 prev_fc2_gb=ew.blocks[li - 1].fc2.gb if li > 0 else None)
             saved_blocks[li] = None
             if on_layer_done is not None:
@@ -316,7 +321,10 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
     n_tok = len(pw.mask_tokens)
     acc = beta != 0.0
     dtn = _linear_backward(dzhat, tn, pw.proj, alpha, beta=beta)
-    dt = ops.layernorm_bwd(dtn, t, pw.norm.g, mean, rstd, pw.norm.gg, pw.norm.gb, alpha=alpha, accumulate=acc)
+    # the trunk's output gradient is dt on the target rows and zero on the context rows, so the last block's fc2 bias gradient
+    # (column sums over ALL rows of that gradient) is the column sum of dt: it comes out of this LayerNorm backward
+    last_gb = pw.blocks[-1].fc2.gb if _tn_ok(8, 8) else None
+    dt = ops.layernorm_bwd(dtn, t, pw.norm.g, mean, rstd, pw.norm.gg, pw.norm.gb, alpha=alpha, accumulate=acc, dxsum=last_gb)
     total = segs[-1].row0 + segs[-1].rows
     dx = torch.zeros((total, Dp), dtype=torch.bfloat16, device=dzhat.device)  # context rows start at zero grad
     for sg, psg, tsg in zip(enc_segs, segs, tsegs):
@@ -327,11 +335,12 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
         side = side_stream(dzhat.device)
         dx = chain.blocks_backward(dx, saved_blocks, pw, alpha, side.stream.cuda_stream if side.enabled else None,
                                    (lambda li: on_layer_done("pred", li)) if on_layer_done is not None else None,
-                                   beta_acc=beta, tag=ws_tag)
+                                   beta_acc=beta, tag=ws_tag, last_fc2_bias_done=last_gb is not None)
     else:
         nb = len(pw.blocks)
         for li in range(nb - 1, -1, -1):
-            dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha, beta, fc2_bias_done=li + 1 < nb,
+            dx = block_backward(dx, saved_blocks[li], pw.blocks[li], segs, pw.heads, alpha, beta,
+                                fc2_bias_done=li + 1 < nb or last_gb is not None,
                                 prev_fc2_gb=pw.blocks[li - 1].fc2.gb if li > 0 else None)
             saved_blocks[li] = None
             if on_layer_done is not None:

@@ -34,6 +34,10 @@ class VjBlock(ctypes.Structure):            # vj_block_t
                 ("fc2", VjLinear)]
 
 
+class VjReduceSeg(ctypes.Structure):        # vj_reduce_seg_t
+    _fields_ = [("part", P), ("out", P), ("P", I64), ("N", I64), ("stride", I64)]
+
+
 class VjSeg(ctypes.Structure):              # vj_seg_t
     _fields_ = [("row0", I64), ("B", I64), ("S", I64)]
 
@@ -56,6 +60,8 @@ SIGNATURES = {
     "vj_layernorm_bwd": (I32, [P, P, P, P, P, P, P, P, P, F32, F32, I64, I64, P, I64, P]),
     "vj_layernorm_bwd_colsum": (I32, [P, P, P, P, P, P, P, P, P, P, F32, F32, I64, I64, P, I64, P]),
     "vj_gemm_bf16_nt": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, P, P, I64, I32, F32, F32, I32, P]),
+    "vj_gemm_colsum_rows": (I64, [I64]),
+    "vj_gemm_bf16_nt_dgelu_colsum": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, P, I64, P, I64, I32, ctypes.POINTER(I32), P]),
     "vj_gemm_bf16_nt_splitk": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, F32, F32, I32, P, I64, P]),
     "vj_gemm_bf16_tn_splitk": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, F32, F32, P, I64, P]),
     "vj_gemm_bf16_tn_grouped": (I32, [P, I64, I64, F32, F32, P, I64, P]),
@@ -66,10 +72,13 @@ SIGNATURES = {
     "vj_colsum_ws_bytes": (I64, [I64]),
     "vj_colsum_bf16": (I32, [P, I64, I64, I64, I64, I64, I64, P, F32, F32, P, I64, P]),
     "vj_reduce_partials": (I32, [P, P, I64, I64, F32, F32, P]),
+    "vj_reduce_segments": (I32, [P, I64, F32, F32, P]),
     "vj_attn_fwd": (I32, [P, P, P, I64, I64, I64, I64, F32, P]),
     "vj_attn_set_variant": (I32, [I32]),
     "vj_attn_bwd_ws_bytes": (I64, [I64, I64, I64]),
     "vj_attn_bwd": (I32, [P, P, P, P, P, I64, I64, I64, I64, F32, P, I64, P]),
+    "vj_attn_bwd_colsum_rows": (I32, [I64, I64, I64, I64P, I64P]),
+    "vj_attn_bwd_colsum": (I32, [P, P, P, P, P, I64, I64, I64, I64, F32, P, I64, P, P, P]),
     "vj_xattn_fwd": (I32, [P, I64, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
     "vj_xattn_bwd": (I32, [P, I64, P, P, P, P, P, I64, I64, I64, I64, I64, F32, P]),
     "vj_pred_assemble_fwd": (I32, [P, P, P, P, P, P, I64, I64, I64, I64, P]),

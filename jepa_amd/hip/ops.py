@@ -335,6 +335,55 @@ def attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
     return dqkv
 
 
+def attn_bwd_colsum(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
+    """attn_bwd + fp32 column partials of dqkv over this segment (vj_attn_bwd_colsum): returns (dqkv, colq [rows_q, H*hd],
+    colkv [rows_kv, 2*H*hd]); the qkv bias gradient is colq.sum(0) | colkv.sum(0) (reduce_segments on the product path)."""
+    import ctypes
+    lib = load_library()
+    _req(dout, BF16, "dout")
+    dqkv = torch.empty_like(qkv) if out is None else out
+    rq, rkv = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib.vj_attn_bwd_colsum_rows(B, S, hd, ctypes.byref(rq), ctypes.byref(rkv)), "vj_attn_bwd_colsum_rows")
+    colq = torch.empty((rq.value, H * hd), dtype=F32, device=qkv.device)
+    colkv = torch.empty((rkv.value, 2 * H * hd), dtype=F32, device=qkv.device)
+    nws = lib.vj_attn_bwd_ws_bytes(B, S, H)
+    ws = Scratch.get(nws, qkv.device, "attn", stream=stream)
+    check(lib.vj_attn_bwd_colsum(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), B, S, H, hd, scale, _ptr(ws), nws,
+                                 _ptr(colq), _ptr(colkv), _stream(stream)), "vj_attn_bwd_colsum")
+    return dqkv, colq, colkv
+
+
+def gemm_dgelu_colsum(dy, wT, aux_in, stream=None):
+    """fc2 dgrad with fc1's bias-gradient partials (vj_gemm_bf16_nt_dgelu_colsum): returns (du bf16 [M, N], colpart fp32
+    [rows, N] or None when the fused kernel did not take the problem -- du is the plain GEMM's either way)."""
+    import ctypes
+    lib = load_library()
+    _req(dy, BF16, "dy")
+    M, K = dy.shape
+    N = wT.shape[0]
+    du = torch.empty((M, N), dtype=BF16, device=dy.device)
+    rows = lib.vj_gemm_colsum_rows(M)
+    colpart = torch.empty((rows, N), dtype=F32, device=dy.device)
+    fused = ctypes.c_int(0)
+    check(lib.vj_gemm_bf16_nt_dgelu_colsum(_ptr(dy), dy.stride(0), _ptr(wT), wT.stride(0), _ptr(du), N, M, N, K, _ptr(aux_in),
+                                           aux_in.stride(0), _ptr(colpart), rows, 0, ctypes.byref(fused), _stream(stream)),
+          "vj_gemm_bf16_nt_dgelu_colsum")
+    return du, (colpart if fused.value else None)
+
+
+def reduce_segments(segs, alpha=1.0, accumulate=False, stream=None):
+    """segs: list of (part fp32 [P, stride] (a 2-D tensor or a column slice of one), out fp32 [N]) -> out = alpha * column sums
+    (+ old when accumulating), all in ONE launch (vj_reduce_segments)."""
+    from .lib import VjReduceSeg
+    lib = load_library()
+    arr = (VjReduceSeg * len(segs))()
+    for i, (part, out) in enumerate(segs):
+        if part.dtype != F32 or out.dtype != F32 or not part.is_cuda or part.dim() != 2 or part.stride(1) != 1:
+            raise ValueError("reduce_segments: partials must be 2-D fp32 GPU tensors with unit column stride")
+        arr[i] = VjReduceSeg(part.data_ptr(), out.data_ptr(), part.shape[0], out.numel(), part.stride(0))
+    check(lib.vj_reduce_segments(arr, len(segs), alpha, 1.0 if accumulate else 0.0, _stream(stream)), "vj_reduce_segments")
+
+
 # ---------------------------------------------------------------- predictor / loss
 def xattn_fwd(q, kv, B, NQ, N, H, hd, scale, resid=None, shared_q=True, save_lse=True, stream=None):
     """Few-query cross-attention (vj_xattn_fwd): q [NQ, D] (shared_q) or [B, NQ, D], kv [B*N, 2*D] packed -> out [B*NQ, D] bf16,

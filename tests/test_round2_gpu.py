@@ -57,8 +57,17 @@ def test_c_chain_is_bit_identical_to_python_chain():
         finally:
             layers.USE_C_CHAIN = True
     assert res[True][0] == res[False][0]
-    for a, b in zip(res[True][1:], res[False][1:]):
-        assert torch.equal(a, b)
+    # round 4: the C chain takes the qkv / fc1 bias gradients from column partials of the kernels that produce dqkv / du (option
+    # bias_fuse, fp32 sums of the un-rounded values), the per-kernel Python chain from the stand-alone column sums of the bf16
+    # dY: those tensors (and, after AdamW, their weights) agree to rounding, everything else stays bit-identical
+    from tests.test_round4_gpu import fused_bias_mask
+    m = fused_bias_mask(tr)
+    for k, (a, b) in enumerate(zip(res[True][1:3], res[False][1:3])):
+        assert torch.equal(a[~m], b[~m]), k
+        assert rel_l2(a[m].cpu(), b[m].cpu()) < 3e-3, (k, rel_l2(a[m].cpu(), b[m].cpu()))
+    mt = fused_bias_mask(tr, tr.tarena)          # the EMA target follows the encoder's biases
+    assert torch.equal(res[True][3][~mt], res[False][3][~mt])
+    assert rel_l2(res[True][3][mt].cpu(), res[False][3][mt].cpu()) < 1e-4
 
 
 def test_micro_batches_accumulate_to_the_full_batch_gradient():
@@ -508,7 +517,10 @@ def test_full_size_step_properties_vitl_b24():
     l1, g1, _ = run()
     assert l1 == l0 and torch.equal(g1, g0), "the step is not deterministic run-to-run"
     lp, gp, _ = run(c_chain=False)
-    assert lp == l0 and torch.equal(gp, g0), "C launch chain and Python chain diverge at full size"
+    from tests.test_round4_gpu import fused_bias_mask
+    fm = fused_bias_mask(tr)     # (the qkv / fc1 bias gradients take the fused route in the C chain only, see test_round4_gpu.py)
+    assert lp == l0 and torch.equal(gp[~fm], g0[~fm]), "C launch chain and Python chain diverge at full size"
+    assert rel_l2(gp[fm].cpu(), g0[fm].cpu()) < 3e-3
     for mb in (12, 9):
         lm, gm, _ = run(mb=mb)
         assert abs(lm - l0) <= 1e-6 * abs(l0), (mb, lm, l0)

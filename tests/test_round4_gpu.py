@@ -1,0 +1,286 @@
+"""Round-4 GPU tests: the seeded soft-max attention kernels (option attn_softmax) against the round-3 kernels and fp32
+PyTorch, the re-base paths of the forward, bias-gradient column partials out of the producing kernels (attention backward,
+fc2-dgrad epilogue), the one-launch segmented reduction, and the block chain with / without option bias_fuse.
+Stated tolerances are next to each assertion; every kernel is reached through the C ABI."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.golden_util import rel_l2  # noqa: E402
+from tests.step_util import TINY, TINY_MASKS, build_trainer, draw_batch, to_dev  # noqa: E402
+from tests.test_kernels_gpu import ATTN_SHAPES, bf, sdpa_ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from jepa_amd.hip import ops as o
+    return o
+
+
+def _gens(masks=TINY_MASKS, m=TINY):
+    from oracle import vjepa_oracle as O
+    return O.make_mask_gens(masks, m["crop"], m["frames"], m["patch"], m["tubelet"])
+
+
+class _opt:
+    """with _opt("name", value): ... restores the previous value."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        from jepa_amd.hip.lib import set_option
+        self.old = set_option(self.name, self.value)
+
+    def __exit__(self, *a):
+        from jepa_amd.hip.lib import set_option
+        set_option(self.name, self.old)
+
+
+# ------------------------------------------------------------------------------------------ seeded soft-max attention
+@pytest.mark.parametrize("B,S,H,hd", ATTN_SHAPES)
+def test_seeded_softmax_attention_matches_round3_kernels_and_fp32(ops, B, S, H, hd):
+    """Option attn_softmax = 1 (scale folded into the stationary operand with one more bf16 rounding, score accumulators
+    seeded with -max / -lse, OR-of-exponent-bits re-base test, head_dim 24 row sums on the V pad column) against fp32 SDPA
+    with the SAME bounds as the round-3 kernels (8e-3 forward, 1.5e-2 backward), and against the round-3 kernels themselves
+    (<= 6e-3 forward / 1.2e-2 backward: two bf16 pipelines of the same arithmetic)."""
+    g = torch.Generator().manual_seed(9)
+    qkv = bf(torch.randn(B * S, 3 * H * hd, generator=g)).to(DEV)
+    dout = bf(torch.randn(B * S, H * hd, generator=g)).to(DEV)
+    scale = hd ** -0.5
+    res = {}
+    for sm in (0, 1):
+        with _opt("attn_softmax", sm):
+            o, lse = ops.attn_fwd(qkv, B, S, H, hd, scale)
+            dqkv = ops.attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale)
+            torch.cuda.synchronize()
+        res[sm] = (o.clone(), lse.clone(), dqkv.clone())
+    x = qkv.float().requires_grad_(True)
+    o_ref = sdpa_ref(x, B, S, H, hd)
+    q, k, _ = x.detach().view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q @ k.transpose(-1, -2)) * scale, -1) / math.log(2.0)
+    o_ref.backward(dout.float())
+    gref = x.grad.view(B, S, 3, H, hd)
+    for sm in (0, 1):
+        o, lse, dqkv = res[sm]
+        e = rel_l2(o, o_ref)
+        assert e < 8e-3, ("fwd", sm, e)
+        assert torch.allclose(lse, lse_ref, rtol=1e-3, atol=2e-2), (sm, float((lse - lse_ref).abs().max()))
+        gout = dqkv.float().view(B, S, 3, H, hd)
+        for i, name in enumerate(["dq", "dk", "dv"]):
+            e = rel_l2(gout[:, :, i], gref[:, :, i])
+            assert e < 1.5e-2, (name, sm, e)
+    assert rel_l2(res[1][0], res[0][0].float()) < 6e-3
+    assert rel_l2(res[1][2], res[0][2].float()) < 1.2e-2
+
+
+@pytest.mark.parametrize("hd", [64, 24, 80])
+def test_seeded_softmax_rebase_paths(ops, hd):
+    """The forward keeps its base 2^5 above the largest score seen when the base was set and re-bases (exact maximum) only when
+    a probability reaches 2.0.  Rows built to hit every path, against fp32 SDPA (max abs error 3e-2 as in the round-3
+    forced-rescale test):
+      row 1: scores rise by ~+8 (log2 units) at every key tile -> a re-base per tile;
+      row 2: first tile far below zero (-60), later tiles around zero -> large upward re-base after a tiny first base;
+      row 3: one key in the LAST tile 160 log2 units above everything -> exp2 overflows to +inf in the fast path (caught by
+             the exponent test) and the re-based recomputation must be exact;
+      row 4: all scores equal (the base never moves);  every other row random."""
+    B, S, H = 1, 300, 1
+    g = torch.Generator().manual_seed(10)
+    t = torch.randn(B, S, 3, H, hd, generator=g)
+    c = 1.0 / (hd ** -0.5 * math.log2(math.e))          # raw q.k product per log2 unit of score
+    t[0, :, 1, 0, 0] = 0.0                              # key feature 0 is the handle: score += q0 * k0
+    t[0, :, 0, 0, 0] = 0.0
+    t[0, 1, 0, 0, 0] = 1.0
+    t[0, :, 1, 0, 0] = (torch.arange(S) // 64).float() * 8.0 * c          # seen by query row 1 only (q0 = 1)
+    t[0, 2, 0, 0] = 0.0
+    t[0, 2, 0, 0, 1] = 1.0
+    t[0, :, 1, 0, 1] = 0.0
+    t[0, :64, 1, 0, 1] = -60.0 * c                                        # query row 2: first tile at -60
+    t[0, 3, 0, 0] = 0.0
+    t[0, 3, 0, 0, 2] = 4.0
+    t[0, :, 1, 0, 2] = 0.0
+    t[0, 290, 1, 0, 2] = 40.0 * c                                         # query row 3: key 290 at +160
+    t[0, 4, 0, 0] = 0.0
+    qkv = bf(t.reshape(B * S, -1)).to(DEV)
+    with _opt("attn_softmax", 1):
+        o, lse = ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5)
+    ref = sdpa_ref(qkv, B, S, H, hd)
+    assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
+    assert float((o.float() - ref).abs().max()) < 3e-2, float((o.float() - ref).abs().max())
+    # and the backward consumes that lse (row 3: P is one-hot on key 290)
+    dout = bf(torch.randn(B * S, H * hd, generator=g)).to(DEV)
+    with _opt("attn_softmax", 1):
+        dqkv = ops.attn_bwd(qkv, o, dout, lse, B, S, H, hd, hd ** -0.5)
+    x = qkv.float().requires_grad_(True)
+    sdpa_ref(x, B, S, H, hd).backward(dout.float())
+    assert bool(torch.isfinite(dqkv.float()).all())
+    assert rel_l2(dqkv, x.grad) < 2e-2, rel_l2(dqkv, x.grad)
+
+
+# ------------------------------------------------------------------------------------------ bias-gradient column partials
+@pytest.mark.parametrize("B,S,H,hd", [(2, 366, 16, 64), (3, 107, 16, 64), (2, 1113, 4, 24), (1, 65, 2, 24), (2, 200, 2, 80),
+                                      (1, 129, 2, 128), (3, 52, 3, 32)])
+@pytest.mark.parametrize("kt", [0, 1, 2])
+def test_attention_backward_column_partials(ops, B, S, H, hd, kt):
+    """vj_attn_bwd_colsum: dqkv bit-identical to vj_attn_bwd; the partial rows summed = column sums over the segment's tokens of
+    the fp32 dQ | dK | dV (before their bf16 rounding): against the sums of the bf16 dqkv to 4e-3 rel-L2 (the rounding of
+    B*S addends), and every partial row is written (NaN-poisoned buffers come back finite)."""
+    g = torch.Generator().manual_seed(31)
+    qkv = bf(torch.randn(B * S, 3 * H * hd, generator=g)).to(DEV)
+    dout = bf(torch.randn(B * S, H * hd, generator=g)).to(DEV)
+    scale = hd ** -0.5
+    with _opt("attn_dkdv_kt", kt):
+        o, lse = ops.attn_fwd(qkv, B, S, H, hd, scale)
+        d0 = ops.attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale).clone()
+        d1, colq, colkv = ops.attn_bwd_colsum(qkv, o, dout, lse, B, S, H, hd, scale)
+        torch.cuda.synchronize()
+    assert torch.equal(d0, d1)
+    assert bool(torch.isfinite(colq).all()) and bool(torch.isfinite(colkv).all())
+    ref = d1.float().view(B * S, 3, H * hd).sum(0)                  # [3, H*hd]
+    got = torch.cat([colq.sum(0), colkv.sum(0)]).view(3, H * hd)
+    for i, name in enumerate(["dq", "dk", "dv"]):
+        e = rel_l2(got[i], ref[i])
+        assert e < 4e-3, (name, e)
+
+
+@pytest.mark.parametrize("M,N,K", [(10560, 4096, 1024), (10000, 4096, 1024), (9999 // 8 * 8, 1536, 384), (300, 512, 256)])
+def test_fc2_dgrad_epilogue_column_partials(ops, M, N, K):
+    """vj_gemm_bf16_nt_dgelu_colsum: du bit-identical to the plain EPI_DGELU GEMM; where the persistent kernel takes the problem
+    the partial rows sum to the column sums of the fp32 product (A W^T) * gelu' over ALL M rows exactly once -- M = 10000 has a
+    SHIFTED last row tile (240 rows shared with its neighbour: counting them twice would be a 2.4 % error) -- to 1e-3 rel-L2
+    against an fp32 PyTorch product; small problems fall back (no partials) and stay correct."""
+    g = torch.Generator().manual_seed(41)
+    A = bf(torch.randn(M, K, generator=g) / math.sqrt(K)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g)).to(DEV)
+    aux = bf(torch.rand(M, N, generator=g) * 1.2 - 0.1).to(DEV)      # gelu' lives in [-0.13, 1.13]
+    plain = ops.gemm_nt(A, W, aux_in=aux, epilogue=ops.EPI_DGELU)
+    du, colpart = ops.gemm_dgelu_colsum(A, W, aux)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, du)
+    if M >= 4096:
+        assert colpart is not None, "the persistent kernel should take this shape"
+        assert bool(torch.isfinite(colpart).all())
+        ref = ((A.float() @ W.float().t()) * aux.float()).sum(0)
+        e = rel_l2(colpart.sum(0), ref)
+        assert e < 1e-3, e
+    else:
+        assert colpart is None
+
+
+def test_reduce_segments_matches_single_reductions(ops):
+    """One launch, several independent reductions (ragged N, strided partial matrices, accumulate): bitwise equal to
+    vj_reduce_partials run per segment, and close to torch's sums."""
+    from jepa_amd.hip.lib import check, load_library
+    g = torch.Generator().manual_seed(51)
+    big = torch.randn(37, 3 * 192, generator=g).to(DEV)              # LayerNorm-style [nb][dgamma | dbeta | colsum]
+    p2 = torch.randn(330, 96, generator=g).to(DEV)                   # N % 64 != 0
+    p3 = torch.randn(5, 1024, generator=g).to(DEV)                   # fewer partial rows than partial lanes
+    outs = [torch.randn(192, generator=g).to(DEV) for _ in range(3)] + [torch.randn(96, generator=g).to(DEV),
+                                                                       torch.randn(1024, generator=g).to(DEV)]
+    segs = [(big[:, 0:192], outs[0]), (big[:, 192:384], outs[1]), (big[:, 384:576], outs[2]), (p2, outs[3]), (p3, outs[4])]
+    for alpha, acc in ((1.0, False), (0.25, True)):
+        old = [o.clone() for o in outs]
+        single = []
+        lib = load_library()
+        for (part, _), o0 in zip(segs, old):
+            o = o0.clone()
+            if part.stride(0) == part.shape[1]:
+                check(lib.vj_reduce_partials(part.data_ptr(), o.data_ptr(), part.shape[0], part.shape[1], alpha, 1.0 if acc else 0.0,
+                                             None), "vj_reduce_partials")
+            else:
+                c = part.contiguous()
+                check(lib.vj_reduce_partials(c.data_ptr(), o.data_ptr(), c.shape[0], c.shape[1], alpha, 1.0 if acc else 0.0, None),
+                      "vj_reduce_partials")
+            single.append(o)
+        ops.reduce_segments(segs, alpha=alpha, accumulate=acc)
+        torch.cuda.synchronize()
+        for (part, out), s1, o0 in zip(segs, single, old):
+            assert torch.equal(out, s1)
+            ref = alpha * part.double().sum(0) + (o0.double() if acc else 0.0)
+            assert rel_l2(out.double().cpu(), ref.cpu()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ the chain with / without bias_fuse
+def fused_bias_mask(tr, arena=None):
+    """bool mask over a parameter arena (default: the trainable one): True on the qkv / fc1 biases (the only gradients option
+    bias_fuse changes)."""
+    arena = tr.arena if arena is None else arena
+    lo = getattr(arena, "lo", 0)                 # the EMA target arena covers the encoder range [lo, hi) of the trainer arena
+    m = torch.zeros(arena.P.numel(), dtype=torch.bool, device=arena.P.device)
+    for name, sl in arena.slots.items():
+        if name.endswith("attn.qkv.bias") or name.endswith("mlp.fc1.bias"):
+            m[sl.off - lo:sl.off - lo + sl.numel] = True
+    return m
+
+
+def test_block_chain_bias_fuse_changes_only_the_fused_biases():
+    """One step on the same weights / batch with option bias_fuse = 1 and 0: the loss and every gradient except the qkv / fc1
+    biases are BIT-identical (the segmented reduction keeps the summation order of the single reductions; the last block's fc2
+    bias comes out of the final-norm backward in both), and the fused biases -- fp32 sums of the un-rounded dY instead of sums
+    of the bf16 dY -- agree to 3e-3 rel-L2 per tensor.  TINY model: sequences of 16-48 tokens (partial-row bound, GEMMs below
+    the persistent kernel's size -> the fc1 bias silently takes the unfused route: both must stay correct)."""
+    tr, _, _, _, _ = build_trainer(TINY, 2, perturb_small=True)
+    clips, me, mp = draw_batch(_gens(), 4, TINY, 61, 62)
+    cd, med, mpd = to_dev(clips, me, mp)
+    res = {}
+    for bfz in (1, 0):
+        with _opt("bias_fuse", bfz):
+            o = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
+            torch.cuda.synchronize()
+        res[bfz] = (o.loss, tr.arena.G.clone())
+    assert res[1][0] == res[0][0]
+    m = fused_bias_mask(tr)
+    assert torch.equal(res[1][1][~m], res[0][1][~m])
+    for name, sl in tr.arena.slots.items():
+        if name.endswith("attn.qkv.bias") or name.endswith("mlp.fc1.bias"):
+            a, b = res[1][1][sl.off:sl.off + sl.numel], res[0][1][sl.off:sl.off + sl.numel]
+            assert rel_l2(a.cpu(), b.cpu()) < 3e-3, (name, rel_l2(a.cpu(), b.cpu()))
+
+
+@pytest.mark.timeout(900)
+def test_block_chain_bias_fuse_vitl_b24_and_micro_batches():
+    """The same at the benched size (ViT-L/16 16x224x224, B = 24: every fused route active -- attention partials for sequences
+    of 48-1248 tokens, the fc2-dgrad epilogue sums on the persistent kernel incl. shifted last row tiles), run-to-run bitwise
+    determinism of the fused path, and gradient accumulation over micro-batches of 12 through the fused path (beta = 1 on the
+    one reduction launch): arena rel-L2 <= 2e-5 against the full batch."""
+    from oracle import vjepa_oracle as O
+    from tests.step_util import VITL, VITL_MASKS
+    tr, _, _, _, _ = build_trainer(VITL, 2)
+    gens = O.make_mask_gens(VITL_MASKS, VITL["crop"], VITL["frames"], VITL["patch"], VITL["tubelet"])
+    clips, me, mp = draw_batch(gens, 24, VITL, 1234, 4321)
+    cd, med, mpd = to_dev(clips, me, mp)
+
+    def run(bfz, mb=None):
+        tr.micro_batch = mb
+        try:
+            with _opt("bias_fuse", bfz):
+                o = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
+                torch.cuda.synchronize()
+            return o.loss, tr.arena.G.clone()
+        finally:
+            tr.micro_batch = None
+    l1, g1 = run(1)
+    l1b, g1b = run(1)
+    assert l1 == l1b and torch.equal(g1, g1b), "the fused path is not deterministic run-to-run"
+    l0, g0 = run(0)
+    assert l1 == l0
+    m = fused_bias_mask(tr)
+    assert torch.equal(g1[~m], g0[~m])
+    worst = 0.0
+    for name, sl in tr.arena.slots.items():
+        if name.endswith("attn.qkv.bias") or name.endswith("mlp.fc1.bias"):
+            e = rel_l2(g1[sl.off:sl.off + sl.numel].cpu(), g0[sl.off:sl.off + sl.numel].cpu())
+            worst = max(worst, e)
+            assert e < 3e-3, (name, e)
+    print(f"bias_fuse 1 vs 0 at ViT-L B=24: worst fused-bias rel-L2 {worst:.2e}")
+    lm, gm = run(1, mb=12)
+    assert abs(lm - l1) <= 1e-6 * abs(l1)
+    r = float((gm.double() - g1.double()).norm() / g1.double().norm())
+    assert r < 2e-5, r
