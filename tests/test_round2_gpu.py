@@ -44,7 +44,9 @@ def test_c_chain_is_bit_identical_to_python_chain():
     """vj_blocks_fwd / vj_blocks_bwd enqueue the same kernels in the same order as the per-kernel Python chain:
     losses, every gradient and every updated weight must be BIT-identical (split-K is deterministic)."""
     from jepa_amd.engine import layers
+    from jepa_amd.hip.lib import set_option
     res = {}
+    old_bf = set_option("bias_fuse", 0)   # the Python chain has no fused bias route; bias_fuse 1 vs 0 is covered in test_round4_gpu.py
     for use_c in (True, False):
         layers.USE_C_CHAIN = use_c
         gens = _gens()    # fresh generators: their step counters seed the block sizes (multiblock3d.py:114-128)
@@ -56,6 +58,8 @@ def test_c_chain_is_bit_identical_to_python_chain():
             res[use_c] = (out.loss, tr.arena.G.clone(), tr.arena.P.clone(), tr.tarena.P.clone())
         finally:
             layers.USE_C_CHAIN = True
+            if not use_c:
+                set_option("bias_fuse", old_bf)
     assert res[True][0] == res[False][0]
     # round 4: the C chain takes the qkv / fc1 bias gradients from column partials of the kernels that produce dqkv / du (option
     # bias_fuse, fp32 sums of the un-rounded values), the per-kernel Python chain from the stand-alone column sums of the bf16

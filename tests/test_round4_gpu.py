@@ -109,19 +109,33 @@ def test_seeded_softmax_rebase_paths(ops, hd):
     t[0, 290, 1, 0, 2] = 40.0 * c                                         # query row 3: key 290 at +160
     t[0, 4, 0, 0] = 0.0
     qkv = bf(t.reshape(B * S, -1)).to(DEV)
-    with _opt("attn_softmax", 1):
-        o, lse = ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5)
     ref = sdpa_ref(qkv, B, S, H, hd)
-    assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
-    assert float((o.float() - ref).abs().max()) < 3e-2, float((o.float() - ref).abs().max())
+    # The folded scale costs one more bf16 rounding of the stationary operand, i.e. 2^-9 RELATIVE on every score: the ramp row
+    # (scores up to 32 log2 units) carries up to 0.06 units of it = 4 % on a probability, the one-hot row (160) more, and the dK/dV
+    # kernel (scale on K) and the forward (scale on Q) round differently.  Rows built on scores of that size are therefore
+    # reproduced to a few per cent, not to bf16 precision; at |score| <= 10 the same term is <= 1.4 % and the random-input cases
+    # above stay at 3e-3.  Bounds: forward max abs error 1e-1 (folded scale) / 3e-2 (round-3 kernels); backward rel-L2 4e-2 / 2e-2.
+    for sm, bound in ((1, 1e-1), (0, 3e-2)):
+        with _opt("attn_softmax", sm):
+            o, lse = ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5)
+        assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
+        err = (o.float() - ref).abs()
+        print(f"adversarial rows hd={hd} attn_softmax={sm}: forward max abs error {float(err.max()):.3e} "
+              f"(rows 1-4: {[round(float(err[r].max()), 4) for r in (1, 2, 3, 4)]}, other rows {float(err[5:].max()):.3e})")
+        assert float(err.max()) < bound, (sm, float(err.max()))
+        assert float(err[5:].max()) < 3e-2        # rows with ordinary scores are unaffected
     # and the backward consumes that lse (row 3: P is one-hot on key 290)
     dout = bf(torch.randn(B * S, H * hd, generator=g)).to(DEV)
-    with _opt("attn_softmax", 1):
-        dqkv = ops.attn_bwd(qkv, o, dout, lse, B, S, H, hd, hd ** -0.5)
     x = qkv.float().requires_grad_(True)
     sdpa_ref(x, B, S, H, hd).backward(dout.float())
-    assert bool(torch.isfinite(dqkv.float()).all())
-    assert rel_l2(dqkv, x.grad) < 2e-2, rel_l2(dqkv, x.grad)
+    for sm, bound in ((1, 4e-2), (0, 2e-2)):
+        with _opt("attn_softmax", sm):
+            o2, lse2 = ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5)
+            dqkv = ops.attn_bwd(qkv, o2, dout, lse2, B, S, H, hd, hd ** -0.5)
+        assert bool(torch.isfinite(dqkv.float()).all())
+        e = rel_l2(dqkv, x.grad)
+        print(f"adversarial rows hd={hd} attn_softmax={sm}: backward rel-L2 {e:.2e}")
+        assert e < bound, (sm, e)
 
 
 # ------------------------------------------------------------------------------------------ bias-gradient column partials
@@ -145,9 +159,13 @@ def test_attention_backward_column_partials(ops, B, S, H, hd, kt):
     assert bool(torch.isfinite(colq).all()) and bool(torch.isfinite(colkv).all())
     ref = d1.float().view(B * S, 3, H * hd).sum(0)                  # [3, H*hd]
     got = torch.cat([colq.sum(0), colkv.sum(0)]).view(3, H * hd)
+    # the column sums of dK vanish in exact arithmetic (sum_k dS[q,k] = 0: a bias on k shifts every score of a query alike), so
+    # both sides hold rounding noise there: errors are measured against the size of the dQ / dV sums
+    size = float(torch.stack([ref[0], ref[2]]).norm()) / math.sqrt(2.0)
     for i, name in enumerate(["dq", "dk", "dv"]):
-        e = rel_l2(got[i], ref[i])
+        e = float((got[i] - ref[i]).norm()) / size
         assert e < 4e-3, (name, e)
+    assert float(got[1].norm()) <= float(ref[1].norm()) * 1.5 + 1e-3 * size   # the fp32 sums are at least as close to zero
 
 
 @pytest.mark.parametrize("M,N,K", [(10560, 4096, 1024), (10000, 4096, 1024), (9999 // 8 * 8, 1536, 384), (300, 512, 256)])

@@ -21,10 +21,39 @@ def main():
     ap.add_argument("--only-fwd", action="store_true")
     ap.add_argument("--shapes", default="")
     ap.add_argument("--fwd-qt", type=int, default=2)
+    ap.add_argument("--sm", default="", help="comma list of attn_softmax option values to run one after the other (e.g. 0,1)")
+    ap.add_argument("--errors", action="store_true", help="also print rel-L2 of o / dq / dk / dv against fp32 SDPA (small B)")
     args = ap.parse_args()
     dev = "cuda"
     from jepa_amd.hip.lib import load_library
     load_library().vj_attn_set_variant(args.fwd_qt)
+    from jepa_amd.hip.lib import get_option, set_option
+    sms = [int(v) for v in args.sm.split(",") if v.strip()] or [get_option("attn_softmax")]
+    for sm in sms:
+        set_option("attn_softmax", sm)
+        print(f"--- attn_softmax = {sm}", flush=True)
+        run_shapes(args, dev)
+
+
+def errors(ops, B, S, H, hd):
+    """rel-L2 against fp32 SDPA on min(B, 2) samples"""
+    import torch.nn.functional as F
+    Bs = min(B, 2)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = torch.randn(Bs * S, 3 * H * hd, device="cuda", generator=g).to(torch.bfloat16)
+    dout = torch.randn(Bs * S, H * hd, device="cuda", generator=g).to(torch.bfloat16)
+    o, lse = ops.attn_fwd(qkv, Bs, S, H, hd, hd ** -0.5)
+    dqkv = ops.attn_bwd(qkv, o, dout, lse, Bs, S, H, hd, hd ** -0.5)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = x.view(Bs, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(Bs * S, H * hd)
+    ref.backward(dout.float())
+    rl = lambda a, b: float((a.float() - b).norm() / b.norm())
+    gr, go = x.grad.view(Bs, S, 3, H, hd), dqkv.float().view(Bs, S, 3, H, hd)
+    return [rl(o, ref)] + [rl(go[:, :, i], gr[:, :, i]) for i in range(3)]
+
+
+def run_shapes(args, dev):
     g = torch.Generator(device=dev).manual_seed(0)
     for tag, B, S, H, hd in SHAPES:
         if args.shapes and tag.split()[0] not in args.shapes:
@@ -50,6 +79,9 @@ def main():
         if not args.only_fwd:
             ms_b = timeit(lambda: ops.attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale))
             line += f" | bwd {ms_b * 1e3:8.1f} us {2 * fl / ms_b / 1e9:7.1f} TF/s"
+        if args.errors:
+            e = errors(ops, B, S, H, hd)
+            line += " | rel-L2 o %.2e dq %.2e dk %.2e dv %.2e" % tuple(e)
         print(line, flush=True)
 
 
