@@ -1198,7 +1198,7 @@ extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int
                      (const bf16_t*)qkv, (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb)
     switch (pick_hdp(hd)) {
       case 32:
-        if (hd == 24) VJ_FWD_SM(32, 3, true);
+        if (hd == 24 && vj_opt(VJ_OPT_ATTN_PSUM) != 0) VJ_FWD_SM(32, 3, true);
         else VJ_FWD_SM(32, 3, false);
         break;
       case 64: VJ_FWD_SM(64, 2, false); break;

@@ -215,7 +215,11 @@ static int check_segs(const vj_seg_t* segs, int64_t n_segs, int64_t M, const cha
 extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M,
                              int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save,
                              int gemm_flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
-  const int fwd_flags = gemm_flags ? gemm_flags : vj_opt(VJ_OPT_GEMM_FWD_FLAGS);
+  // gemm_flags: low 16 bits = kernel selection of vj_gemm_bf16_nt (0: option gemm_fwd_flags); bits 16-23 = first block the
+  // selection applies to (earlier blocks take the automatic choice) -- the EMA target encoder's late blocks run after the
+  // context branch has left the GPU, where the two-workgroups-per-CU kernel (0x100) is the faster one
+  const int sel_flags = (gemm_flags & 0xffff) ? (gemm_flags & 0xffff) : vj_opt(VJ_OPT_GEMM_FWD_FLAGS);
+  const int64_t sel_from = (gemm_flags >> 16) & 0xff;
   CH(check_blocks(blocks, n_blocks, D, "vj_blocks_fwd"));
   CH(check_segs(segs, n_segs, M, "vj_blocks_fwd"));
   VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_fwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
@@ -232,6 +236,7 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
   const char* x = (const char*)x_in;
   for (int64_t li = 0; li < n_blocks; li++) {
     const vj_block_t& b = blocks[li];
+    const int fwd_flags = li >= sel_from ? sel_flags : vj_opt(VJ_OPT_GEMM_FWD_FLAGS);
     char* w = save ? base + li * L.total : base;
     char* x2;
     if (li == n_blocks - 1) x2 = (char*)x_out;

@@ -89,8 +89,10 @@ __device__ __forceinline__ void pp_tile_origin(const GemmArgs& p, int logical, i
 
 enum { PP_STEADY = 0, PP_HEAD0, PP_HEAD1, PP_TAIL0, PP_TAIL1 };
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p) {
+// SCHED = 8: the round-3 schedule (four {load, compute} pairs per K-tile, 16 MFMAs per compute section);
+// SCHED = 4 (round 4): TWO pairs per K-tile, 32 MFMAs per compute section -- see k_tile4 below.
+template <int EPI, int SCHED>
+__device__ __forceinline__ void pp_body(const GemmArgs& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,6 +287,63 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
   using M_TAIL0 = std::integral_constant<int, PP_TAIL0>;
   using M_TAIL1 = std::integral_constant<int, PP_TAIL1>;
 
+  // ---- SCHED = 4: one K-tile = TWO {load section, barrier, compute section, barrier}:
+  //   LX(t): rb0 <- B0(t), rb1 <- B1(t);  issue A1(t+1), A0(t+2);  CX(t): quadrants 00, 01 (ra0 x rb0, rb1: 32 MFMAs)
+  //   LY(t): ra1 <- A1(t), ra0 <- A0(t+1); issue B0(t+2), B1(t+2); CY(t): quadrants 11, 10 (ra1 x rb1, rb0: 32 MFMAs)
+  // Why: a section boundary costs a SIMD a fixed ~80 cycles whatever the section holds (barrier release, the partner's load
+  // segment next to the MFMAs, the role switch: MI355X_MICROARCH.md "two waves per SIMD", items 5-7; measured here: 337 cycles
+  // per 256-cycle MFMA section).  Halving the boundaries per K-tile halves that cost relative to the matrix time (8 x 337 ->
+  // 4 x ~595 cycles per K-tile).  Same part STREAM as the 8-section schedule (..., A1(t+1), A0(t+2), B0(t+2), B1(t+2), ...), two
+  // parts per load section and half a K-tile earlier, so the prologue / cross-tile prefetch hand the next tile the same seven
+  // parts; same fragment registers (a section only loads registers whose last MFMA is behind the previous barrier); same MFMA
+  // order per accumulator, hence bit-identical results.  Ring safety: LX(t) writes half h(t+1) slots 2, 3 = A1(t-1) | A0(t),
+  // last read in LY(t-1) (>= 2 sections earlier for both wave groups); LY(t) writes half h(t) slots 0, 1 = B0(t) | B1(t), last
+  // read in LX(t).  Waits: a load section leaves at most the 8 youngest DMA instructions in flight (the two parts it issued and
+  // the two parts of the section before): the parts the NEXT load section reads were issued before those.  K-tile 0 waits for
+  // nothing (its parts and K-tile 1's landed before the epilogue's vmcnt(0)), so the previous tile's stores drain under 64 MFMAs.
+  auto k_tile4 = [&](auto mode_tag, int t, int h) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool HEAD0 = MODE == PP_HEAD0, TAIL0 = MODE == PP_TAIL0, TAIL1 = MODE == PP_TAIL1;
+    const char* half_c = smem + h * 4 * PP_PART;
+    const int ho = h ^ 1;
+    // ---------------- LX
+    read_b(rb0, half_c + 0 * PP_PART);
+    read_b(rb1, half_c + 1 * PP_PART);
+    if constexpr (TAIL1) {
+      issue_next(K_A1{}, a0n, b0n, 0, ho);
+      issue_next(K_A0{}, a0n, b0n, 1, ho);
+    } else if constexpr (TAIL0) {
+      issue(K_A1{}, cur, t + 1, ho);
+      issue_next(K_A0{}, a0n, b0n, 0, ho);
+    } else {
+      issue(K_A1{}, cur, t + 1, ho);
+      issue(K_A0{}, cur, t + 2, ho);
+    }
+    if constexpr (!HEAD0) pp_wait<8>();
+    pp_bar();
+    mma(Q00{}, rb0, ra0);
+    mma(Q01{}, rb1, ra0);
+    pp_bar();
+    // ---------------- LY
+    read_a(ra1, half_c + 2 * PP_PART);
+    if constexpr (!TAIL1) read_a(ra0, half_c + 3 * PP_PART);   // (the next tile's A0(0) is read at its start, after the epilogue)
+    if constexpr (TAIL1) {
+      issue_next(K_B0{}, a0n, b0n, 1, h);
+      issue_next(K_B1{}, a0n, b0n, 1, h);
+    } else if constexpr (TAIL0) {
+      issue_next(K_B0{}, a0n, b0n, 0, h);
+      issue_next(K_B1{}, a0n, b0n, 0, h);
+    } else {
+      issue(K_B0{}, cur, t + 2, h);
+      issue(K_B1{}, cur, t + 2, h);
+    }
+    if constexpr (!HEAD0 && !TAIL1) pp_wait<8>();
+    pp_bar();
+    mma(Q11{}, rb1, ra1);
+    mma(Q10{}, rb0, ra1);
+    pp_bar();
+  };
+
   // ---- first tile: parts -1 .. 5 in flight, all landed before anybody reads
   int64_t m0, n0;
   int tm_cur;                                  // un-shifted row-tile index of the current tile (column-sum slot / row ownership)
@@ -313,20 +372,28 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
       for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     // ---- tile start: part 6 = A1(1) -> half h^1 slot 2 (its previous content, A1 of the previous tile's last K-tile, was
     //      read >= 2 sections + one epilogue ago); every other part up to 5 landed before this wave's last vmcnt(0)
-    issue(K_A1{}, cur, 1, h ^ 1);
+    if constexpr (SCHED == 8) issue(K_A1{}, cur, 1, h ^ 1);   // (SCHED = 4 issues it in LX(0))
     pp_bar();
     if (late_group) pp_bar();
     read_a(ra0, smem + ((h ^ 1) * 4 + 3) * PP_PART);   // L(-1): A0(0)
     pp_bar();
     pp_bar();
-    k_tile(M_HEAD0{}, 0, h);
-    k_tile(M_HEAD1{}, 1, h ^ 1);
-    int t = 2;
-    for (; t < nk - 2; t++) k_tile(M_STEADY{}, t, h ^ (t & 1));
-    // ONE tail for every tile: the last tile "prefetches" its own first parts again (never read; retired by the
-    // epilogue's vmcnt(0)).  A has_next diamond around two copies of the tail costs ~300 spilled VGPRs (hipcc 7.2).
-    k_tile(M_TAIL0{}, nk - 2, h ^ (nk & 1));
-    k_tile(M_TAIL1{}, nk - 1, h ^ ((nk - 1) & 1));
+    if constexpr (SCHED == 8) {
+      k_tile(M_HEAD0{}, 0, h);
+      k_tile(M_HEAD1{}, 1, h ^ 1);
+      int t = 2;
+      for (; t < nk - 2; t++) k_tile(M_STEADY{}, t, h ^ (t & 1));
+      // ONE tail for every tile: the last tile "prefetches" its own first parts again (never read; retired by the
+      // epilogue's vmcnt(0)).  A has_next diamond around two copies of the tail costs ~300 spilled VGPRs (hipcc 7.2).
+      k_tile(M_TAIL0{}, nk - 2, h ^ (nk & 1));
+      k_tile(M_TAIL1{}, nk - 1, h ^ ((nk - 1) & 1));
+    } else {
+      k_tile4(M_HEAD0{}, 0, h);
+      int t = 1;
+      for (; t < nk - 2; t++) k_tile4(M_STEADY{}, t, h ^ (t & 1));
+      k_tile4(M_TAIL0{}, nk - 2, h ^ (nk & 1));
+      k_tile4(M_TAIL1{}, nk - 1, h ^ ((nk - 1) & 1));
+    }
     if (!late_group) pp_bar();   // the early group matches the late group's extra barrier
     h ^= (nk & 1);               // ring half of the next tile's K-tile 0
 
@@ -353,6 +420,15 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
     tm_cur = tm_next;
     pp_make_bases(cur, a0n, b0n, lda2, ldb2);
   }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p) {
+  pp_body<EPI, 8>(p);
+}
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_4phase_persist_kernel(GemmArgs p) {
+  pp_body<EPI, 4>(p);
 }
 
 int g_num_cus = 0;   // CU count of the (homogeneous) GPUs of this node, read once
@@ -410,7 +486,15 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
     if (per_xcd * 8 > g_num_cus) per_xcd = g_num_cus / 8;
     grid = (int)(per_xcd * 8);
   }
-  hipLaunchKernelGGL(gemm_nt_8phase_persist_kernel<EPI>, dim3(grid), dim3(512), smem, stream, b);
+  if (vj_opt(VJ_OPT_GEMM_SCHED) == 4) {
+    static VjPerDeviceOnce attr4_once;
+    attr4_once([] {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    });
+    hipLaunchKernelGGL(gemm_nt_4phase_persist_kernel<EPI>, dim3(grid), dim3(512), smem, stream, b);
+  } else {
+    hipLaunchKernelGGL(gemm_nt_8phase_persist_kernel<EPI>, dim3(grid), dim3(512), smem, stream, b);
+  }
   VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase)");
   return 0;
 }

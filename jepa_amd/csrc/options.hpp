@@ -31,6 +31,9 @@ enum VjOpt {
                                // 0: stand-alone column-sum kernels re-reading dY
   VJ_OPT_GELU_POLY,            // 1 (default, round 4): erf of the no-backward GELU epilogue by an odd minimax polynomial (no v_rcp /
                                // v_exp); 0: Abramowitz-Stegun 7.1.26
+  VJ_OPT_GEMM_SCHED,           // load / compute section pairs per K-tile of the persistent NT GEMM: 8 = four pairs of 16 MFMAs (round 3),
+                               // 4 = two pairs of 32 MFMAs (round 4: half the section boundaries); bit-identical results
+  VJ_OPT_ATTN_PSUM,            // 1 (default): head_dim 24 forward takes its row sums from the V pad column (P.V MFMA); 0: vector adds
   VJ_OPT_COUNT
 };
 

@@ -227,7 +227,7 @@ def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], sa
         tok = torch.empty((r, kdim), dtype=torch.bfloat16, device=clips.device)
         for sg, m in zip(segs, masks):
             ops.tubelet_pack(clips, ew.tubelet, ew.patch_size, idx=m, out=_rows(tok, sg))
-    x = ops.gemm_nt(tok, ew.patch.w, bias=ew.patch.b, flags=gemm_flags or None)
+    x = ops.gemm_nt(tok, ew.patch.w, bias=ew.patch.b, flags=(gemm_flags & 0xffff if not gemm_flags >> 16 else 0) or None)
     for i, sg in enumerate(segs):
         ops.add_pos(_rows(x, sg), ew.pos, sg.B, sg.S, idx=None if masks is None else masks[i])
     if ws_tag is not None and USE_C_CHAIN:    # ws_tag: the caller owns one workspace per trunk (engine/chain.py)

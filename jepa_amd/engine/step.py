@@ -103,6 +103,9 @@ class StepOutput:
 
 import os as _os
 _OVERLAP_FWD = _os.environ.get("VJ_OVERLAP_FWD", "1") != "0"   # diagnostics: 0 = target forward on the main stream
+# GEMM kernel selection of the EMA target encoder's forward (vj_blocks_fwd gemm_flags: low 16 bits = flags, bits 16-23 = first
+# block they apply to); 0 = automatic everywhere
+_TGT_GEMM_FLAGS = int(_os.environ.get("VJ_TGT_GEMM_FLAGS", "0"), 0)
 
 
 def _strip(name):
@@ -188,7 +191,8 @@ class Trainer:
     def forward_target(self, clips, masks_pred):
         """h_i = apply_masks(F.layer_norm(target_encoder(clips)), masks_pred)  (train.py:419-429), fp32."""
         B = clips.shape[0]
-        x, _, _ = encoder_forward(self.tw, clips, None, save=False, final_norm=False, ws_tag=self._ws + "tgt")
+        x, _, _ = encoder_forward(self.tw, clips, None, save=False, final_norm=False, ws_tag=self._ws + "tgt",
+                                  gemm_flags=_TGT_GEMM_FLAGS)
         N = self.tvit.num_patches
         return [ops.target_rows(x, self.tw.norm.g, self.tw.norm.b, mp, B, N, 1e-6, 1e-5) for mp in masks_pred]
 

@@ -58,7 +58,7 @@ def test_c_chain_is_bit_identical_to_python_chain():
             res[use_c] = (out.loss, tr.arena.G.clone(), tr.arena.P.clone(), tr.tarena.P.clone())
         finally:
             layers.USE_C_CHAIN = True
-            if not use_c:
+            if not use_c or use_c not in res:
                 set_option("bias_fuse", old_bf)
     assert res[True][0] == res[False][0]
     # round 4: the C chain takes the qkv / fc1 bias gradients from column partials of the kernels that produce dqkv / du (option

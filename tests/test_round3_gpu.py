@@ -102,14 +102,20 @@ def test_persistent_gemm_is_bit_identical_to_the_one_tile_kernel(M, N, K):
             old = set_option("gemm_persist", 0)
             try:
                 ref, ref_aux = _run_gemm(*ops_in, epi, with_aux)
-                for mode in (1, 2):   # 1: trimmed grid (default), 2: one workgroup per CU
+                # mode 1: trimmed grid (default), 2: one workgroup per CU; sched 8: four {load, compute} section pairs per K-tile,
+                # 4 (round 4): two pairs of 32 MFMAs -- every combination must give the one-tile kernel's bits
+                for mode, sched in ((1, 8), (2, 8), (1, 4), (2, 4)):
                     set_option("gemm_persist", mode)
-                    got, got_aux = _run_gemm(*ops_in, epi, with_aux)
-                    torch.cuda.synchronize()
-                    assert not torch.isnan(got.float()).any(), (mode, epi, with_res, with_aux, seed, "unwritten output")
-                    assert torch.equal(got, ref), (mode, epi, with_res, with_aux, seed, int((got != ref).sum()))
+                    old_s = set_option("gemm_sched", sched)
+                    try:
+                        got, got_aux = _run_gemm(*ops_in, epi, with_aux)
+                        torch.cuda.synchronize()
+                    finally:
+                        set_option("gemm_sched", old_s)
+                    assert not torch.isnan(got.float()).any(), (mode, sched, epi, with_res, with_aux, seed, "unwritten output")
+                    assert torch.equal(got, ref), (mode, sched, epi, with_res, with_aux, seed, int((got != ref).sum()))
                     if with_aux:
-                        assert torch.equal(got_aux, ref_aux), (mode, epi, seed, "aux")
+                        assert torch.equal(got_aux, ref_aux), (mode, sched, epi, seed, "aux")
             finally:
                 set_option("gemm_persist", old)
         A, W, bias, res, aux_in = ops_in

@@ -34,7 +34,8 @@ def main():
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     from jepa_amd.hip.lib import set_option
-    # "4.0" = flags 0x100 (gemm4w.hip); "8.0" = automatic selection with the persistent 8-phase kernel (gemm8p.hip) enabled
+    # "4.0" = flags 0x100 (gemm4w.hip); "8.0" = automatic selection with the persistent 8-phase kernel (gemm8p.hip) enabled;
+    # "8.4" = the same with option gemm_sched = 4 (two section pairs of 32 MFMAs per K-tile)
     cfgs = [tuple(int(v) for v in c.split(".")) for c in args.cfgs.split(",")]
     print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " + " ".join(f"t{c}p{q}(TF/s)" for c, q in cfgs))
     for tag, M, N, K, epi in (STEP_SHAPES if args.no_wgrad else SHAPES):
@@ -47,6 +48,7 @@ def main():
         for c, q in cfgs:
             flags = 0x100 if c == 4 else (0 if c == 8 else (c << 4) | (q << 6))
             set_option("gemm_persist", 1 if c == 8 else 0)
+            set_option("gemm_sched", 4 if (c == 8 and q == 4) else 8)
 
             def run():
                 if epi == 3:
