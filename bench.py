@@ -355,7 +355,7 @@ def main():
             log(f"exposed communication (compute stream blocked in reducer.finish): {ex:.2f} ms/step over the last "
                 f"{trainer.reducer.exposed_samples} steps")
             ex = max_over_ranks(ex, world, device)
-        dp_info = {"ranks": world, "backend": "rccl via " + ("vj_comm_* (C ABI)" if trainer.reducer._capi else "torch.distributed"),
+        dp_info = {"ranks": world, "backend": "rccl via torch.distributed",
                    "layer_buckets": len(trainer.reducer.buckets), "tail_ranges": len(trainer.reducer.tail),
                    "grad_bytes_per_step": int(trainer.arena.total * 4),
                    "exposed_comm_ms_per_step": None if ex is None else round(ex, 3),

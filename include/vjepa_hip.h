@@ -81,6 +81,9 @@ int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, const float
  *             the only thing the backward needs from u)
  *           2 bf16 out = acc * aux_in, aux_in = what epilogue 1 saved   (fc2 dgrad fused with the GELU backward)
  *           3 fp32 out = alpha*acc + beta*C            (wgrad straight into the fp32 gradient arena)
+ *           4 bf16 out = (acc + bias) * (n < N/3 ? alpha : 1)   (the qkv projection of Attention, modules.py:63, whose q part carries
+ *             the soft-max scale alpha = head_dim^-0.5 * log2(e) with ONE rounding; the attention entry points are then called with
+ *             a NEGATIVE scale = "q is pre-scaled"; N % 12 == 0, no residual)
  * K % 32 == 0, N % 4 == 0, lda/ldb % 8 == 0.  flags bit0: register-staged operand path (A/B testing). */
 int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                     int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
@@ -149,8 +152,20 @@ int vj_reduce_segments(const vj_reduce_seg_t* segs, int64_t n_segs, float alpha,
  * F.scaled_dot_product_attention(q,k,v) (modules.py:66-69): dense, non-causal, scale = head_dim^-0.5.
  * qkv: packed qkv-Linear output [B,S,3,H,hd] (modules.py:63 before the permute); o: [B,S,H*hd];
  * lse2: [B,H,S] fp32 log2-sum-exp saved for the backward (nullable in inference).  hd % 8 == 0, hd <= 128. */
+/* scale > 0: the kernels fold scale*log2(e) into the stationary operand of the score product themselves (one more bf16 rounding
+ * of q / k); scale < 0: the caller's qkv GEMM already stored q * |scale| * log2(e) (epilogue 4 above) -- same for the backward. */
 int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd, float scale,
                 vj_stream_t stream);
+/* The same for n_segs <= 4 segments of ONE token-major activation in one launch -- the rows of the masks of a V-JEPA batch
+ * are concatenated (MultiMaskWrapper loops over them, src/models/utils/multimask.py:17-27): qkv [M, 3*H*hd], o [M, H*hd],
+ * lse2 [H*M] with segment i's block [B_i, H, S_i] at offset H*row0_i.  The short segment's workgroups fill the tail of the
+ * long one instead of paying their own launch. */
+typedef struct vj_seg {
+  int64_t row0; /* first token row of the segment */
+  int64_t B, S; /* rows row0 .. row0 + B*S are B sequences of S tokens */
+} vj_seg_t;
+int vj_attn_fwd_segs(const void* qkv, void* o, float* lse2, const vj_seg_t* segs, int64_t n_segs, int64_t H, int64_t hd,
+                     float scale, vj_stream_t stream);
 /* tuning switch (benchmarks only): 16-row query tiles per wave in the forward kernel, 2 (default) or 1 */
 int vj_attn_set_variant(int fwd_qt);
 int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H);
@@ -166,6 +181,11 @@ int vj_attn_bwd_colsum_rows(int64_t B, int64_t S, int64_t hd, int64_t* rows_q, i
 int vj_attn_bwd_colsum(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B,
                        int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, float* colq,
                        float* colkv, vj_stream_t stream);
+/* backward over n_segs <= 4 segments in one launch pair (dQ, then dK/dV); ws >= 4*H*M bytes; colq / colkv (both or neither,
+ * nullable): the column partials, segment after segment in list order */
+int vj_attn_bwd_segs(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, const vj_seg_t* segs,
+                     int64_t n_segs, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, float* colq,
+                     float* colkv, vj_stream_t stream);
 
 /* ---- cross-attention of a few learned queries against frozen-encoder tokens (attentive probe, row f4 widened) ------
  * CrossAttention.forward (src/models/utils/modules.py:140-157) as used by CrossAttentionBlock (modules.py:177-181) inside
@@ -267,9 +287,7 @@ typedef struct vj_block {
   vj_norm_t norm2;
   vj_linear_t fc1, fc2;
 } vj_block_t;
-typedef struct vj_seg {
-  int64_t row0, B, S; /* B sequences of S tokens in rows [row0, row0 + B*S) */
-} vj_seg_t;
+/* (vj_seg_t: declared with the attention entry points above) */
 typedef void (*vj_layer_cb_t)(void* user, int layer);
 
 /* save != 0: every block keeps what its backward needs (16*D bf16 per token: x, LN1 out, qkv, o, x1, LN2 out,

@@ -20,6 +20,7 @@
 // saves for the backward (an internal format, produced and consumed only here).
 #include "common.hpp"
 #include "options.hpp"
+#include "../../include/vjepa_hip.h"
 #include <type_traits>
 #include <cstdlib>
 
@@ -224,6 +225,27 @@ __device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* p, bool valid
   u32x4_t v = {0, 0, 0, 0};
   if (valid) v = *(const u32x4_t*)p;
   return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// Several [B_i, S_i] segments of one token-major activation (the two masks of a V-JEPA batch) in ONE launch: the workgroups of
+// the short segment fill the tail of the long one instead of paying a launch of their own (ViT-L context encoder: 376- and
+// 112-token segments, the second alone runs at 90-280 TF/s).  Workgroup -> (segment, local index) by the cumulative counts.
+#define VJ_ATTN_MAX_SEGS 4
+struct AttnSegs {
+  int n;
+  int blk_end[VJ_ATTN_MAX_SEGS];    // cumulative workgroup counts
+  int S[VJ_ATTN_MAX_SEGS];          // sequence length
+  int nb[VJ_ATTN_MAX_SEGS];         // query blocks (forward, dQ) or key blocks (dK/dV) per (sample, head)
+  int64_t row0[VJ_ATTN_MAX_SEGS];   // first token row of the segment
+  int64_t col0[VJ_ATTN_MAX_SEGS];   // first column-partial row of the segment (backward with column sums)
+};
+__device__ __forceinline__ int attn_seg_of(const AttnSegs& sg, int& logical) {
+  int si = 0;
+#pragma unroll
+  for (int i = 0; i + 1 < VJ_ATTN_MAX_SEGS; i++)
+    if (i + 1 < sg.n && logical >= sg.blk_end[i]) si = i + 1;
+  logical -= si > 0 ? sg.blk_end[si - 1] : 0;
+  return si;
 }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -467,9 +489,9 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
 // forward, round 4 ("seeded" soft-max, see SM_HEADROOM above): same tiling, staging and MFMA layout as attn_fwd_kernel
 // =============================================================================================================
 template <int HDP, int QT, int NBUF, bool PSUM>
-__global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                          float* __restrict__ lse2, int B, int S, int H, int hd,
-                                                          float sc, int nqb) {
+__global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* __restrict__ qkv_all,
+                                                          bf16_t* __restrict__ o_all, float* __restrict__ lse2_all,
+                                                          AttnSegs sg, int H, int hd, float sc) {
   constexpr int NT = 8 * 64 / QT;
   using RT = RowTile<HDP, NT>;
   constexpr int DIST = NBUF - 1;
@@ -481,10 +503,15 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
   constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int si = attn_seg_of(sg, logical);
+  const int S = sg.S[si], nqb = sg.nb[si];
+  const int64_t rs = (int64_t)3 * H * hd;
+  const bf16_t* qkv = qkv_all + sg.row0[si] * rs;
+  bf16_t* o = o_all + sg.row0[si] * ((int64_t)H * hd);
+  float* lse2 = lse2_all ? lse2_all + (int64_t)H * sg.row0[si] : nullptr;
   const int qb = logical % nqb, bh = logical / nqb;
   const int h = bh % H, b = bh / H;
-  const int64_t rs = (int64_t)3 * H * hd;
   const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
   const bf16_t* kbase = qbase + (int64_t)H * hd;
   const int q0 = qb * 128 + w * (16 * QT);
@@ -731,12 +758,12 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
 // and their transposed reads do not depend on the key, so KT = 2 reuses every one of them for two key tiles.
 // =============================================================================================================
 template <int HDP, int KT, bool SM>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv,
-                                                            const bf16_t* __restrict__ dout,
-                                                            const float* __restrict__ lse2,
-                                                            const float* __restrict__ delta,
-                                                            bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
-                                                            float sc, float scale, int nkb, float* __restrict__ colkv) {
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv_all,
+                                                            const bf16_t* __restrict__ dout_all,
+                                                            const float* __restrict__ lse2_all,
+                                                            const float* __restrict__ delta_all,
+                                                            bf16_t* __restrict__ dqkv_all, AttnSegs sg, int H, int hd,
+                                                            float sc, float scale, float* __restrict__ colkv) {
   // two {Q, dO} images filled by LDS-DMA (tile t+1 lands while tile t is multiplied) + two {lse, delta} rows; one
   // barrier per tile
   constexpr int BUFB = 2 * RowTile<HDP>::BYTES;
@@ -746,11 +773,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
   constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int kb = logical % nkb, bh = logical / nkb;
-  const int h = bh % H, b = bh / H;
+  int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int si = attn_seg_of(sg, logical);
+  const int S = sg.S[si], nkb = sg.nb[si];
   const int64_t rs = (int64_t)3 * H * hd;
   const int64_t os = (int64_t)H * hd;
+  const bf16_t* qkv = qkv_all + sg.row0[si] * rs;
+  const bf16_t* dout = dout_all + sg.row0[si] * os;
+  const float* lse2 = lse2_all + (int64_t)H * sg.row0[si];
+  const float* delta = delta_all + (int64_t)H * sg.row0[si];
+  bf16_t* dqkv = dqkv_all + sg.row0[si] * rs;
+  if (colkv != nullptr) colkv += sg.col0[si] * (2 * os);
+  const int kb = logical % nkb, bh = logical / nkb;
+  const int h = bh % H, b = bh / H;
   const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
   const bf16_t* kbase = qbase + (int64_t)H * hd;
   const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
@@ -964,13 +999,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 //   anyway plus one read of its O rows, and written to `delta` for the dK/dV kernel, which is launched after this one:
 //   the separate delta pass (one more kernel on the critical path of every attention backward) is gone.
 template <int HDP, bool SM>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv,
-                                                          const bf16_t* __restrict__ o,
-                                                          const bf16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse2,
-                                                          float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int B, int S, int H, int hd,
-                                                          float sc, float scale, int nqb, float* __restrict__ colq) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv_all,
+                                                          const bf16_t* __restrict__ o_all,
+                                                          const bf16_t* __restrict__ dout_all,
+                                                          const float* __restrict__ lse2_all,
+                                                          float* __restrict__ delta_all,
+                                                          bf16_t* __restrict__ dqkv_all, AttnSegs sg, int H, int hd,
+                                                          float sc, float scale, float* __restrict__ colq) {
   // {K,V} x NBUF ring filled by LDS-DMA (see the forward kernel): one barrier per tile, tile t+DIST in flight
   constexpr int NBUF = HDP <= 64 ? 3 : 2, DIST = NBUF - 1, BUFB = 2 * RowTile<HDP>::BYTES, RINGB = NBUF * BUFB;
   __shared__ __attribute__((aligned(16))) char smem[RINGB];
@@ -978,11 +1013,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = logical % nqb, bh = logical / nqb;
-  const int h = bh % H, b = bh / H;
+  int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int si = attn_seg_of(sg, logical);
+  const int S = sg.S[si], nqb = sg.nb[si];
   const int64_t rs = (int64_t)3 * H * hd;
   const int64_t os = (int64_t)H * hd;
+  const bf16_t* qkv = qkv_all + sg.row0[si] * rs;
+  const bf16_t* o = o_all + sg.row0[si] * os;
+  const bf16_t* dout = dout_all + sg.row0[si] * os;
+  const float* lse2 = lse2_all + (int64_t)H * sg.row0[si];
+  float* delta = delta_all + (int64_t)H * sg.row0[si];
+  bf16_t* dqkv = dqkv_all + sg.row0[si] * rs;
+  if (colq != nullptr) colq += sg.col0[si] * os;
+  const int qb = logical % nqb, bh = logical / nqb;
+  const int h = bh % H, b = bh / H;
   const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
   const bf16_t* kbase = qbase + (int64_t)H * hd;
   const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
@@ -1177,38 +1221,104 @@ extern "C" int vj_attn_set_variant(int fwd_qt) {
 static int pick_hdp(int64_t hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : (hd <= 80 ? 96 : (hd <= 128 ? 128 : 0))); }
 #define LOG2E 1.4426950408889634f
 
+// segment list -> kernel argument (workgroups per segment = B * H * blocks(S)); empty segments are dropped
+static int make_segs(const vj_seg_t* segs, int64_t n_segs, int64_t H, int64_t rows_per_block, AttnSegs* out, int64_t* nblk,
+                     const char* who) {
+  VJ_CHECK_ARG(segs != nullptr && n_segs >= 1 && n_segs <= VJ_ATTN_MAX_SEGS, "%s: 1..%d segments", who, VJ_ATTN_MAX_SEGS);
+  int k = 0;
+  int64_t tot = 0, col = 0;
+  for (int64_t i = 0; i < n_segs; i++) {
+    VJ_CHECK_ARG(segs[i].B >= 0 && segs[i].S >= 0 && segs[i].row0 >= 0, "%s: bad segment %ld", who, (long)i);
+    if (segs[i].B * segs[i].S == 0) continue;
+    const int64_t nb = cdiv64(segs[i].S, rows_per_block);
+    tot += segs[i].B * H * nb;
+    VJ_CHECK_ARG(tot < (1ll << 31) && segs[i].S < (1ll << 31), "%s: grid too large", who);
+    out->blk_end[k] = (int)tot;
+    out->S[k] = (int)segs[i].S;
+    out->nb[k] = (int)nb;
+    out->row0[k] = segs[i].row0;
+    out->col0[k] = col;
+    col += segs[i].B * nb;
+    k++;
+  }
+  for (int i = k; i < VJ_ATTN_MAX_SEGS; i++) {
+    out->blk_end[i] = (int)tot;
+    out->S[i] = 0;
+    out->nb[i] = 1;
+    out->row0[i] = 0;
+    out->col0[i] = 0;
+  }
+  out->n = k;
+  *nblk = tot;
+  return 0;
+}
+
+static int attn_fwd_old(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd, float scale,
+                        hipStream_t stream);
+
+// One launch over n_segs <= 4 segments of one token-major activation: qkv [M, 3*H*hd], o [M, H*hd], lse2 [H*M] (segment i: rows
+// row0_i .. row0_i + B_i*S_i, its lse2 block at H*row0_i laid out [B_i, H, S_i]).
+extern "C" int vj_attn_fwd_segs(const void* qkv, void* o, float* lse2, const vj_seg_t* segs, int64_t n_segs, int64_t H,
+                                int64_t hd, float scale, hipStream_t stream) {
+  VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_fwd: head_dim=%ld unsupported (need %%8==0, <=128)", (long)hd);
+  VJ_CHECK_ARG(H > 0, "vj_attn_fwd: bad dims");
+  const int64_t rs = 3 * H * hd, os = H * hd;
+  if (vj_opt(VJ_OPT_ATTN_SOFTMAX) == 0 || g_attn_fwd_qt != 2) {   // round-3 kernels: one launch per segment
+    VJ_CHECK_ARG(segs != nullptr && n_segs >= 0, "vj_attn_fwd_segs: bad segment list");
+    for (int64_t i = 0; i < n_segs; i++) {
+      const int rc = attn_fwd_old((const bf16_t*)qkv + segs[i].row0 * rs, (bf16_t*)o + segs[i].row0 * os,
+                                  lse2 ? lse2 + H * segs[i].row0 : nullptr, segs[i].B, segs[i].S, H, hd, scale, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  AttnSegs sg;
+  int64_t nblk = 0;
+  if (int rc = make_segs(segs, n_segs, H, 128, &sg, &nblk, "vj_attn_fwd")) return rc;
+  if (nblk == 0) return 0;
+  // scale < 0: the q part of qkv ALREADY carries |scale| * log2(e) (the qkv GEMM applied it before its bf16 rounding, epilogue 4
+  // of vj_gemm_bf16_nt): the kernels' own factor becomes 1 (scale_frag(x, 1) is the identity)
+  const float sc = scale < 0.f ? 1.0f : scale * LOG2E;
+  // round-4 kernels (seeded soft-max); head_dim 24: row sums on the pad column
+#define VJ_FWD_SM(HDPV, NB, PS)                                                                                       \
+  hipLaunchKernelGGL((attn_fwd_sm_kernel<HDPV, 2, NB, PS>), dim3((unsigned)nblk), dim3(256), 0, stream,                \
+                     (const bf16_t*)qkv, (bf16_t*)o, lse2, sg, (int)H, (int)hd, sc)
+  switch (pick_hdp(hd)) {
+    case 32:
+      if (hd == 24 && vj_opt(VJ_OPT_ATTN_PSUM) != 0) VJ_FWD_SM(32, 3, true);
+      else VJ_FWD_SM(32, 3, false);
+      break;
+    case 64: VJ_FWD_SM(64, 2, false); break;
+    case 96: VJ_FWD_SM(96, 2, false); break;
+    default: VJ_FWD_SM(128, 2, false);
+  }
+#undef VJ_FWD_SM
+  VJ_LAUNCH_CHECK("vj_attn_fwd");
+  return 0;
+}
+
 extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd,
                            float scale, hipStream_t stream) {
+  VJ_CHECK_ARG(B >= 0 && S >= 0 && H > 0, "vj_attn_fwd: bad dims");
+  const vj_seg_t one = {0, B, S};
+  return vj_attn_fwd_segs(qkv, o, lse2, &one, 1, H, hd, scale, stream);
+}
+
+static int attn_fwd_old(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd, float scale,
+                        hipStream_t stream) {
   VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_fwd: head_dim=%ld unsupported (need %%8==0, <=128)", (long)hd);
   VJ_CHECK_ARG(B >= 0 && S >= 0 && H > 0, "vj_attn_fwd: bad dims");
   if (B * S == 0) return 0;
   const int nqb = (int)cdiv64(S, 128);
   const int64_t nblk = B * H * nqb;
   VJ_CHECK_ARG(nblk < (1ll << 31), "vj_attn_fwd: grid too large");
-  const float sc = scale * LOG2E;
+  const float sc = scale < 0.f ? 1.0f : scale * LOG2E;   // (scale < 0: q pre-scaled, see vj_attn_fwd_segs)
   // QT = 16-row query tiles per wave (QT = 1: 8 waves / workgroup, half the registers per wave).  Measured on
   // MI355X: QT = 2 is faster or equal for every head size (the kernel is bound by VALU issue, not by occupancy).
 #define VJ_FWD(HDPV, QTV, NB)                                                                                        \
   hipLaunchKernelGGL((attn_fwd_kernel<HDPV, QTV, NB>), dim3((unsigned)nblk), dim3(8 * 64 / QTV), 0, stream,            \
                      (const bf16_t*)qkv, (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb)
   const int qt_sel = g_attn_fwd_qt;
-  if (vj_opt(VJ_OPT_ATTN_SOFTMAX) != 0 && qt_sel == 2) {   // round-4 kernels (seeded soft-max); head_dim 24: row sums on the pad column
-#define VJ_FWD_SM(HDPV, NB, PS)                                                                                       \
-  hipLaunchKernelGGL((attn_fwd_sm_kernel<HDPV, 2, NB, PS>), dim3((unsigned)nblk), dim3(256), 0, stream,                \
-                     (const bf16_t*)qkv, (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb)
-    switch (pick_hdp(hd)) {
-      case 32:
-        if (hd == 24 && vj_opt(VJ_OPT_ATTN_PSUM) != 0) VJ_FWD_SM(32, 3, true);
-        else VJ_FWD_SM(32, 3, false);
-        break;
-      case 64: VJ_FWD_SM(64, 2, false); break;
-      case 96: VJ_FWD_SM(96, 2, false); break;
-      default: VJ_FWD_SM(128, 2, false);
-    }
-#undef VJ_FWD_SM
-    VJ_LAUNCH_CHECK("vj_attn_fwd");
-    return 0;
-  }
   // ring depth: 2 buffers for hd <= 64 measured equal or faster than 3 (396 vs 408 us on the ViT-L target shape) and
   // leaves 32 KB of LDS, i.e. the forward can share a CU with other work; VJ_ATTN_NBUF=3 selects the deeper ring
   static const int nb_env = [] { const char* e = getenv("VJ_ATTN_NBUF"); return e ? atoi(e) : 0; }();
@@ -1251,14 +1361,67 @@ extern "C" int vj_attn_bwd_colsum_rows(int64_t B, int64_t S, int64_t hd, int64_t
   return 0;
 }
 
-static int attn_bwd_impl(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B, int64_t S,
-                         int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, float* colq, float* colkv,
-                         hipStream_t stream);
+// One launch pair (dQ, then dK/dV) over n_segs <= 4 segments of one token-major activation (layout as vj_attn_fwd_segs; dout / o
+// [M, H*hd], dqkv [M, 3*H*hd], ws >= 4*H*M bytes (delta, laid out like lse2)).  colq / colkv (both or neither): column
+// partials of dqkv, segment after segment in the order of the list (rows per segment: vj_attn_bwd_colsum_rows).
+extern "C" int vj_attn_bwd_segs(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv,
+                                const vj_seg_t* segs, int64_t n_segs, int64_t H, int64_t hd, float scale, void* ws,
+                                int64_t ws_bytes, float* colq, float* colkv, hipStream_t stream) {
+  VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_bwd: head_dim=%ld unsupported", (long)hd);
+  VJ_CHECK_ARG(H > 0 && (colq == nullptr) == (colkv == nullptr), "vj_attn_bwd: bad arguments");
+  const int kt = dkdv_kt(hd);
+  AttnSegs sq, sk;
+  int64_t gq = 0, gk = 0;
+  if (int rc = make_segs(segs, n_segs, H, 128, &sq, &gq, "vj_attn_bwd")) return rc;
+  if (int rc = make_segs(segs, n_segs, H, 64 * kt, &sk, &gk, "vj_attn_bwd")) return rc;
+  if (gq == 0) return 0;
+  int64_t rows_end = 0;   // the delta workspace mirrors lse2: H floats per token row up to the last row of the list
+  for (int64_t i = 0; i < n_segs; i++)
+    if (segs[i].B * segs[i].S > 0 && segs[i].row0 + segs[i].B * segs[i].S > rows_end) rows_end = segs[i].row0 + segs[i].B * segs[i].S;
+  VJ_CHECK_ARG(ws != nullptr && ws_bytes >= rows_end * H * 4, "vj_attn_bwd: workspace too small");
+  float* delta = (float*)ws;
+  // scale < 0: q is stored pre-scaled by c = |scale| * log2(e) (vj_attn_fwd_segs).  The kernels' own score factor is then 1;
+  // dQ = |scale| * dS K is unchanged (the gradient of the UNscaled q: what the qkv dgrad / wgrad expect, since the GEMM's
+  // column scale is part of the forward map), and dK = |scale| * dS^T Q = (|scale| / c) * dS^T Q' = dS^T Q' / log2(e)
+  const bool pre = scale < 0.f;
+  const float sabs = fabsf(scale);
+  const float sc = pre ? 1.0f : sabs * LOG2E;
+  const float kscale = pre ? 1.0f / LOG2E : sabs;
+  // dQ first: it also produces delta[b,h,s] = dO . O for the dK/dV kernel behind it on the same stream.
+  // dK/dV: KTV 16-key tiles per wave (option attn_dkdv_kt: 0 = per head-dim class, 1 / 2 forced)
+#define VJ_BWD_LAUNCH(HDPV, KTV, SMV)                                                                              \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, SMV>), dim3((unsigned)gq), dim3(256), 0, stream,                  \
+                       (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sq,   \
+                       (int)H, (int)hd, sc, sabs, colq);                                                           \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV, SMV>), dim3((unsigned)gk), dim3(256), 0, stream,            \
+                       (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sk, (int)H, (int)hd,    \
+                       sc, kscale, colkv);                                                                         \
+  } while (0)
+#define VJ_BWD_SM(HDPV, KTV)                                     \
+  do {                                                           \
+    if (sm) VJ_BWD_LAUNCH(HDPV, KTV, true);                      \
+    else VJ_BWD_LAUNCH(HDPV, KTV, false);                        \
+  } while (0)
+  const bool sm = vj_opt(VJ_OPT_ATTN_SOFTMAX) != 0;
+  switch (pick_hdp(hd)) {
+    case 32: if (kt == 1) VJ_BWD_SM(32, 1); else VJ_BWD_SM(32, 2); break;
+    case 64: if (kt == 2) VJ_BWD_SM(64, 2); else VJ_BWD_SM(64, 1); break;
+    case 96: VJ_BWD_SM(96, 1); break;
+    default: VJ_BWD_SM(128, 1);
+  }
+#undef VJ_BWD_SM
+#undef VJ_BWD_LAUNCH
+  VJ_LAUNCH_CHECK("vj_attn_bwd");
+  return 0;
+}
 
 extern "C" int vj_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv,
                            int64_t B, int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes,
                            hipStream_t stream) {
-  return attn_bwd_impl(qkv, o, dout, lse2, dqkv, B, S, H, hd, scale, ws, ws_bytes, nullptr, nullptr, stream);
+  VJ_CHECK_ARG(B >= 0 && S >= 0, "vj_attn_bwd: bad dims");
+  const vj_seg_t one = {0, B, S};
+  return vj_attn_bwd_segs(qkv, o, dout, lse2, dqkv, &one, 1, H, hd, scale, ws, ws_bytes, nullptr, nullptr, stream);
 }
 
 // vj_attn_bwd + the column sums of dqkv over this segment's tokens as fp32 partials (the qkv bias gradient, autograd of
@@ -1268,51 +1431,7 @@ extern "C" int vj_attn_bwd(const void* qkv, const void* o, const void* dout, con
 extern "C" int vj_attn_bwd_colsum(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv,
                                   int64_t B, int64_t S, int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes,
                                   float* colq, float* colkv, hipStream_t stream) {
-  VJ_CHECK_ARG(colq != nullptr && colkv != nullptr, "vj_attn_bwd_colsum: null partial buffers");
-  return attn_bwd_impl(qkv, o, dout, lse2, dqkv, B, S, H, hd, scale, ws, ws_bytes, colq, colkv, stream);
-}
-
-static int attn_bwd_impl(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B, int64_t S,
-                         int64_t H, int64_t hd, float scale, void* ws, int64_t ws_bytes, float* colq, float* colkv,
-                         hipStream_t stream) {
-  VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_bwd: head_dim=%ld unsupported", (long)hd);
-  VJ_CHECK_ARG(ws_bytes >= vj_attn_bwd_ws_bytes(B, S, H), "vj_attn_bwd: workspace too small");
-  if (B * S == 0) return 0;
-  float* delta = (float*)ws;
-  const int nqb = (int)cdiv64(S, 128);
-  const int64_t g2 = B * H * nqb;
-  VJ_CHECK_ARG(B * H * cdiv64(S, 64) < (1ll << 31), "vj_attn_bwd: grid too large");
-  const float sc = scale * LOG2E;
-  // dQ first: it also produces delta[b,h,s] = dO . O for the dK/dV kernel behind it on the same stream.
-  // dK/dV: KTV 16-key tiles per wave (option attn_dkdv_kt: 0 = per head-dim class, 1 / 2 forced)
-#define VJ_BWD_LAUNCH(HDPV, KTV)                                                                                   \
-  do {                                                                                                             \
-    const int nkb = (int)cdiv64(S, 64 * KTV);                                                                      \
-    if (sm) {                                                                                                      \
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, true>), dim3((unsigned)g2), dim3(256), 0, stream,               \
-                         (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv,     \
-                         (int)B, (int)S, (int)H, (int)hd, sc, scale, nqb, colq);                                   \
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV, true>), dim3((unsigned)(B * H * nkb)), dim3(256), 0,      \
-                         stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B,       \
-                         (int)S, (int)H, (int)hd, sc, scale, nkb, colkv);                                          \
-    } else {                                                                                                       \
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, false>), dim3((unsigned)g2), dim3(256), 0, stream,              \
-                         (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv,     \
-                         (int)B, (int)S, (int)H, (int)hd, sc, scale, nqb, colq);                                   \
-      hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV, false>), dim3((unsigned)(B * H * nkb)), dim3(256), 0,     \
-                         stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, (int)B,       \
-                         (int)S, (int)H, (int)hd, sc, scale, nkb, colkv);                                          \
-    }                                                                                                              \
-  } while (0)
-  const int kt_opt = vj_opt(VJ_OPT_ATTN_DKDV_KT);
-  const bool sm = vj_opt(VJ_OPT_ATTN_SOFTMAX) != 0;
-  switch (pick_hdp(hd)) {
-    case 32: if (kt_opt == 1) VJ_BWD_LAUNCH(32, 1); else VJ_BWD_LAUNCH(32, 2); break;
-    case 64: if (kt_opt == 2) VJ_BWD_LAUNCH(64, 2); else VJ_BWD_LAUNCH(64, 1); break;
-    case 96: VJ_BWD_LAUNCH(96, 1); break;
-    default: VJ_BWD_LAUNCH(128, 1);
-  }
-#undef VJ_BWD_LAUNCH
-  VJ_LAUNCH_CHECK("vj_attn_bwd");
-  return 0;
+  VJ_CHECK_ARG(colq != nullptr && colkv != nullptr && B >= 0 && S >= 0, "vj_attn_bwd_colsum: bad arguments");
+  const vj_seg_t one = {0, B, S};
+  return vj_attn_bwd_segs(qkv, o, dout, lse2, dqkv, &one, 1, H, hd, scale, ws, ws_bytes, colq, colkv, stream);
 }

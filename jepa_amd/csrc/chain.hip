@@ -231,6 +231,9 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
                (long)vj_blocks_fwd_ws_bytes(M, D, Dh, heads, n_blocks, save));
   VJ_CHECK_ARG(((uintptr_t)ws & 255) == 0, "vj_blocks_fwd: workspace must be 256-byte aligned");
   const FwdLayout L = fwd_layout(M, D, Dh, heads);
+  const bool merge_segs = n_segs > 1 && n_segs <= 4 && vj_opt(VJ_OPT_ATTN_MERGE) != 0;
+  const bool qpre = vj_opt(VJ_OPT_ATTN_SOFTMAX) == 2 && (3 * D) % 12 == 0;
+  const float ascale = qpre ? -scale : scale;   // negative: "q is pre-scaled" (vj_attn_fwd_segs)
   char* base = (char*)ws;
   char* pingpong[2] = {base + L.x, base + L.total};   // save = 0: block outputs alternate between these two
   const char* x = (const char*)x_in;
@@ -247,14 +250,31 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
     float* mean2 = save ? (float*)(w + L.mean2) : nullptr;
     float* rstd2 = save ? (float*)(w + L.rstd2) : nullptr;
     CH(vj_layernorm_fwd(x, b.norm1.g, b.norm1.b, w + L.y1, mean1, rstd1, M, D, ln_eps, stream));
-    CH(gemm(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 0, stream, fwd_flags));
-    for (int64_t s = 0; s < n_segs; s++) {
-      const vj_seg_t& sg = segs[s];
-      if (sg.B * sg.S == 0) continue;
-      float* lse = save ? (float*)(w + L.lse) + heads * sg.row0 : nullptr;
-      ProfScope ps(stream, 1, 4.0 * sg.B * heads * sg.S * sg.S * hd, sg.B, sg.S, heads, (int)hd);
-      CH(vj_attn_fwd(w + L.qkv + sg.row0 * 3 * D * 2, w + L.o + sg.row0 * D * 2, lse, sg.B, sg.S, heads, hd, scale,
-                     stream));
+    if (qpre) {   // option attn_softmax = 2: the q third carries scale * log2(e), applied before the bf16 rounding (epilogue 4)
+      ProfScope ps(stream, 0, 2.0 * M * 3 * D * D, M, 3 * D, D, 0);
+      CH(vj_gemm_bf16_nt(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 4,
+                         scale * 1.4426950408889634f, 0.0f, fwd_flags, stream));
+    } else {
+      CH(gemm(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 0, stream, fwd_flags));
+    }
+    if (merge_segs) {   // all segments (masks) in ONE launch: the short one's workgroups fill the long one's tail
+      double fl = 0;
+      int64_t smax = 0;
+      for (int64_t s = 0; s < n_segs; s++) {
+        fl += 4.0 * segs[s].B * heads * segs[s].S * segs[s].S * hd;
+        if (segs[s].S > smax) smax = segs[s].S;
+      }
+      ProfScope ps(stream, 1, fl, segs[0].B, smax, heads, (int)hd);
+      CH(vj_attn_fwd_segs(w + L.qkv, w + L.o, save ? (float*)(w + L.lse) : nullptr, segs, n_segs, heads, hd, ascale, stream));
+    } else {
+      for (int64_t s = 0; s < n_segs; s++) {
+        const vj_seg_t& sg = segs[s];
+        if (sg.B * sg.S == 0) continue;
+        float* lse = save ? (float*)(w + L.lse) + heads * sg.row0 : nullptr;
+        ProfScope ps(stream, 1, 4.0 * sg.B * heads * sg.S * sg.S * hd, sg.B, sg.S, heads, (int)hd);
+        CH(vj_attn_fwd(w + L.qkv + sg.row0 * 3 * D * 2, w + L.o + sg.row0 * D * 2, lse, sg.B, sg.S, heads, hd, ascale,
+                       stream));
+      }
     }
     CH(gemm(w + L.o, D, b.proj.w, D, w + L.x1, D, M, D, D, b.proj.b, x, D, nullptr, nullptr, 0, 0, stream, fwd_flags));
     CH(vj_layernorm_fwd(w + L.x1, b.norm2.g, b.norm2.b, w + L.y2, mean2, rstd2, M, D, ln_eps, stream));
@@ -493,7 +513,21 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
       if (rows_q > L.colp_attn_rows || rows_kv > L.colp_attn_rows) qkv_fused = false;
     }
     int64_t off_q = 0, off_kv = 0;
-    for (int64_t s = 0; s < n_segs; s++) {
+    const bool merge_segs = n_segs > 1 && n_segs <= 4 && vj_opt(VJ_OPT_ATTN_MERGE) != 0;
+    const float ascale = (vj_opt(VJ_OPT_ATTN_SOFTMAX) == 2 && (3 * D) % 12 == 0) ? -scale : scale;   // as the forward stored q
+    if (merge_segs) {   // one dQ + one dK/dV launch for all segments (partials: segment after segment, as the loop below lays them out)
+      double fl = 0;
+      int64_t smax = 0;
+      for (int64_t s = 0; s < n_segs; s++) {
+        fl += 8.0 * segs[s].B * heads * segs[s].S * segs[s].S * hd;
+        if (segs[s].S > smax) smax = segs[s].S;
+      }
+      ProfScope ps(stream, 2, fl, segs[0].B, smax, heads, (int)hd);
+      CH(vj_attn_bwd_segs(w + F.qkv, w + F.o, tmp + L.dob, (const float*)(w + F.lse), dqkv, segs, n_segs, heads, hd, ascale,
+                          tmp + L.delta, L.delta_bytes, qkv_fused ? (float*)(tmp + L.colp_q) : nullptr,
+                          qkv_fused ? (float*)(tmp + L.colp_kv) : nullptr, stream));
+    }
+    for (int64_t s = 0; s < n_segs && !merge_segs; s++) {
       const vj_seg_t& sg = segs[s];
       if (sg.B * sg.S == 0) continue;
       ProfScope ps(stream, 2, 8.0 * sg.B * heads * sg.S * sg.S * hd, sg.B, sg.S, heads, (int)hd);
@@ -502,13 +536,13 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
         CH(vj_attn_bwd_colsum_rows(sg.B, sg.S, hd, &rq, &rkv));
         CH(vj_attn_bwd_colsum(w + F.qkv + sg.row0 * 3 * D * 2, w + F.o + sg.row0 * D * 2, tmp + L.dob + sg.row0 * D * 2,
                               (const float*)(w + F.lse) + heads * sg.row0, dqkv + sg.row0 * 3 * D * 2, sg.B, sg.S, heads, hd,
-                              scale, tmp + L.delta, L.delta_bytes, (float*)(tmp + L.colp_q) + off_q * D,
+                              ascale, tmp + L.delta, L.delta_bytes, (float*)(tmp + L.colp_q) + off_q * D,
                               (float*)(tmp + L.colp_kv) + off_kv * 2 * D, stream));
         off_q += rq;
         off_kv += rkv;
       } else {
         CH(vj_attn_bwd(w + F.qkv + sg.row0 * 3 * D * 2, w + F.o + sg.row0 * D * 2, tmp + L.dob + sg.row0 * D * 2,
-                       (const float*)(w + F.lse) + heads * sg.row0, dqkv + sg.row0 * 3 * D * 2, sg.B, sg.S, heads, hd, scale,
+                       (const float*)(w + F.lse) + heads * sg.row0, dqkv + sg.row0 * 3 * D * 2, sg.B, sg.S, heads, hd, ascale,
                        tmp + L.delta, L.delta_bytes, stream));
       }
     }

@@ -8,7 +8,12 @@
 // unique id that rank 0 obtains from vj_comm_unique_id and distributes out of band (file, env, MPI, a TCP store).
 #include "common.hpp"
 #include "../../include/vjepa_hip.h"
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <dlfcn.h>
+#include <link.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <rccl/rccl.h>
@@ -30,9 +35,23 @@ std::once_flag g_rccl_once;
 const Rccl& rccl() {
   std::call_once(g_rccl_once, [] {
     const char* names[] = {"librccl.so", "librccl.so.1"};
-    for (const char* n : names) {   // a copy that is already loaded (torch's) wins
-      g_rccl.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    // a copy that is ALREADY mapped into the process wins (PyTorch-ROCm ships its own librccl.so and loads it by path: a lookup
+    // by soname does not find it, and binding the system copy next to it would leave the process with two RCCL runtimes):
+    // walk the loaded objects for a path that names librccl and re-open exactly that file
+    struct Found { char path[1024]; } found = {{0}};
+    dl_iterate_phdr(
+        [](struct dl_phdr_info* info, size_t, void* data) -> int {
+          if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) {
+            strncpy(((Found*)data)->path, info->dlpi_name, sizeof(Found::path) - 1);
+            return 1;
+          }
+          return 0;
+        },
+        &found);
+    if (found.path[0]) g_rccl.h = dlopen(found.path, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names) {
       if (g_rccl.h) break;
+      g_rccl.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     }
     for (int i = 0; i < 2 && !g_rccl.h; i++) g_rccl.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
     if (!g_rccl.h) g_rccl.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -47,6 +66,11 @@ const Rccl& rccl() {
 #undef VJ_SYM
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.Broadcast &&
                 g_rccl.GetErrorString;
+    if (getenv("VJ_COMM_DEBUG")) {   // which librccl did we bind?  (two RCCL runtimes in one process is the thing to avoid)
+      Dl_info info;
+      if (g_rccl.AllReduce && dladdr((void*)g_rccl.AllReduce, &info) && info.dli_fname)
+        fprintf(stderr, "libvjepa_hip: vj_comm_* bound to %s\n", info.dli_fname);
+    }
   });
   return g_rccl;
 }

@@ -334,6 +334,12 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
                (long)ldb, (long)K);
   VJ_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "vj_gemm_bf16_nt: A/B must be 16-byte aligned");
   VJ_CHECK_ARG(ldc % 4 == 0 && ldc >= N, "vj_gemm_bf16_nt: ldc=%ld must be a multiple of 4 and >= N", (long)ldc);
+  float qscale = 0.f;
+  if (epilogue == EPI_QKV_API) {   // qkv projection whose q third carries alpha (= scale * log2 e): bf16 epilogue + column scale
+    VJ_CHECK_ARG(N % 12 == 0 && residual == nullptr && alpha != 0.f, "vj_gemm_bf16_nt: epilogue 4 needs N %% 12 == 0, no residual, alpha != 0");
+    qscale = alpha;
+    epilogue = EPI_BF16;
+  }
   VJ_CHECK_ARG(epilogue >= EPI_BF16 && epilogue <= EPI_F32, "vj_gemm_bf16_nt: unknown epilogue %d", epilogue);
   VJ_CHECK_ARG((uintptr_t)C % (epilogue == EPI_F32 ? 16 : 8) == 0, "vj_gemm_bf16_nt: C misaligned");
   if (epilogue == EPI_DGELU) VJ_CHECK_ARG(aux_in != nullptr && ldaux % 4 == 0, "vj_gemm_bf16_nt: EPI_DGELU needs aux_in");
@@ -347,6 +353,8 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.dbg = vj_opt(VJ_OPT_GEMM_DBG);
   a.zero_row = nullptr;
   a.colpart = nullptr;
+  a.qscale = qscale;
+  a.qcols = qscale != 0.f ? N / 3 : 0;
   switch (epilogue) {
     case EPI_BF16: return dispatch_gemm<EPI_BF16>(a, flags, nullptr, 0, stream);
     case EPI_GELU: return dispatch_gemm<EPI_GELU>(a, flags, nullptr, 0, stream);
@@ -391,6 +399,8 @@ extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const vo
     a.tiles_m = a.tiles_n = 0; a.splitk = 1; a.ktiles_per = 0; a.ws = nullptr;
     a.dbg = 0;
     a.zero_row = nullptr;
+    a.qscale = 0.f;
+    a.qcols = 0;
     a.colpart = colpart;
     const int rc = vj_gemm_launch_8phase_persist(a, EPI_DGELU, stream);
     if (rc != -100) {

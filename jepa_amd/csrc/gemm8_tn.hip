@@ -153,6 +153,8 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
 
   GemmArgs p;
   p.colpart = nullptr;
+  p.qscale = 0.f;
+  p.qcols = 0;
   int logical_all;
   if constexpr (GROUPED) {
     const int l = xcd_logical(blockIdx.x, ga.unit_end[ga.n - 1]);
@@ -406,6 +408,8 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
                         int64_t N1, int64_t N2, float alpha, float beta) {
   GemmArgs b;
   b.colpart = nullptr;
+  b.qscale = 0.f;
+  b.qcols = 0;
   b.A = (const bf16_t*)dY; b.B = (const bf16_t*)X; b.C = dW; b.bias = nullptr; b.res = nullptr; b.aux_in = nullptr;
   b.aux_out = nullptr;
   b.M = N1; b.N = N2; b.K = T; b.lda = ldy; b.ldb = ldx; b.ldc = ldw; b.ldr = 0; b.ldaux = 0;

@@ -3,6 +3,7 @@
 #include "common.hpp"
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_F32 = 3 };
+#define EPI_QKV_API 4   // C-ABI only: EPI_BF16 whose first N/3 output columns (the q part of a qkv projection) are multiplied by alpha
 
 struct GemmArgs {
   const bf16_t* A;
@@ -20,6 +21,8 @@ struct GemmArgs {
   float* ws;
   const bf16_t* zero_row;   // 128 bf16 zeros: source of token rows beyond T in the TN weight-gradient kernel (gemm8_tn.hip)
   int dbg;             // diagnostics (env VJ_GEMM_DBG, tools/gemm_ksweep.py): bit0 = drop the epilogue, bit1 = direct (unstaged) stores
+  float qscale;        // EPI_BF16 without residual: != 0 -> columns n < qcols are multiplied by qscale before the bf16 rounding (the q part
+  int64_t qcols;       //   of a qkv projection carries the soft-max scale scale*log2(e): ONE rounding of c*q, attention.hip); qcols % 4 == 0
   float* colpart;      // EPI_DGELU on the persistent kernel, nullable: fp32 column-sum partials of the OUTPUT, [2 * tiles_m][N]
                        // (row slot = 2 * row tile + wave row): the bias gradient of the Linear whose dY this GEMM produces
 };
@@ -35,10 +38,19 @@ struct GemmArgs {
 // nullable operands are resolved once by the caller-side variant switch (HAS_OPT), the bias is complete before the
 // first row (one explicit wait), and the row operands (residual / saved pre-activation) are fetched one row-block ahead
 // so that a row's stores stay in flight while the next row is computed.
-template <int EPI, int FM, int FN, bool HAS_OPT, bool EDGE, bool BETA = false>
+template <int EPI, int FM, int FN, bool HAS_OPT, bool EDGE, bool BETA = false, bool QS = false>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int64_t m_base,
                                                    int64_t n_base, int frow, int fg, int slice) {
+  static_assert(!QS || (EPI == EPI_BF16 && !HAS_OPT), "column scale: the qkv projection (bf16 output, no residual)");
   const int64_t ncol0 = n_base + fg * 4;   // this lane's first column; tile j adds j*16
+  f32x2_t qs2[QS ? FN : 1];
+  if constexpr (QS) {
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      const float sj = (ncol0 + j * 16 < p.qcols) ? p.qscale : 1.0f;
+      qs2[j] = (f32x2_t){sj, sj};
+    }
+  }
   bool cok[FN];
   int64_t ncl[FN];                         // column for loads, clamped into the matrix (N % 4 == 0, N >= 4)
 #pragma unroll
@@ -116,6 +128,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
       for (int j = 0; j < FN; j++) {
         f32x2_t v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
         f32x2_t v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
+        if constexpr (QS) {
+          v01 *= qs2[j];
+          v23 *= qs2[j];
+        }
         if constexpr (EPI == EPI_GELU) {
           u32x2_t u;
           u[0] = pack_bf2_opaque(v01[0], v01[1]);
@@ -162,7 +178,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 // rows below `row_lo` -- the part of a SHIFTED edge tile that belongs to its neighbour -- are left out) and writes the 64
 // column sums to p.colpart[slot][n_base ..]: du = dY of fc1 is produced here, so fc1's bias gradient costs 64 packed FMAs + 64
 // DPP adds per wave tile instead of a second pass over du (colsum_bf16_kernel: 84 MB per ViT-L context block).
-template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false>
+template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage,
                                                      int64_t row_lo = 0, int slot = 0) {
@@ -230,6 +246,15 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     for (int j = 0; j < FN; j++) dst[j] = *(const u32x2_t*)(base + ncl[j]);
   };
   static_assert(!CSUM || (EPI == EPI_DGELU && !EDGE), "column sums: the fc2-dgrad epilogue of the persistent kernel");
+  static_assert(!QS || (EPI == EPI_BF16 && !HAS_OPT), "column scale: the qkv projection (bf16 output, no residual)");
+  f32x2_t qs2[QS ? FN : 1];
+  if constexpr (QS) {
+#pragma unroll
+    for (int j = 0; j < FN; j++) {
+      const float sj = (ncol0 + j * 16 < p.qcols) ? p.qscale : 1.0f;
+      qs2[j] = (f32x2_t){sj, sj};
+    }
+  }
   f32x2_t cs01[CSUM ? FN : 1], cs23[CSUM ? FN : 1];
   if constexpr (CSUM) {
 #pragma unroll
@@ -254,6 +279,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       for (int j = 0; j < FN; j++) {
         f32x2_t v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
         f32x2_t v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
+        if constexpr (QS) {
+          v01 *= qs2[j];
+          v23 *= qs2[j];
+        }
         u32x2_t o;
         if constexpr (EPI == EPI_GELU) {
           u32x2_t u;
@@ -336,6 +365,13 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
         return true;
       }
     }
+    if constexpr (EPI == EPI_BF16) {
+      if (p.qscale != 0.f && n_base < p.qcols) {   // wave tiles that hold q columns only (the launcher guarantees: no residual)
+        if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        else gemm_epilogue_staged<EPI, false, false, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        return true;
+      }
+    }
     if (opt) {
       if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
       else gemm_epilogue_staged<EPI, true, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
@@ -358,6 +394,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
   // interior wave tiles (the vast majority) carry no predicates at all
   const bool edge =
       !INTERIOR_VARIANT || __builtin_amdgcn_readfirstlane((m_base + FM * 16 > p.M) || (n_base + FN * 16 > p.N));
+  if constexpr (EPI == EPI_BF16) {
+    if (p.qscale != 0.f && n_base < p.qcols) {   // wave tiles that hold q columns only (the launcher guarantees: no residual)
+      if (edge) gemm_epilogue_impl<EPI, FM, FN, false, true, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      else gemm_epilogue_impl<EPI, FM, FN, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      return;
+    }
+  }
   if (opt) {
     if (edge) gemm_epilogue_impl<EPI, FM, FN, true, true>(p, acc, m_base, n_base, frow, fg, slice);
     else gemm_epilogue_impl<EPI, FM, FN, true, false>(p, acc, m_base, n_base, frow, fg, slice);

@@ -25,7 +25,10 @@ enum VjOpt {
   VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)
   VJ_OPT_ATTN_SOFTMAX,         // 1 (default, round 4): attention kernels with the soft-max scale folded into the stationary operand
                                // and the score accumulators seeded with -max / -lse (no per-score FMA, no per-tile row maximum);
-                               // 0: the round-3 kernels (results agree to bf16 rounding, not bitwise)
+                               // 0: the round-3 kernels (results agree to bf16 rounding, not bitwise);
+                               // 2: as 1, but inside the block chains the scale reaches q in the qkv GEMM's epilogue (vj_gemm_bf16_nt
+                               // epilogue 4: one rounding of c*q, no second rounding of the stationary operand) and the attention
+                               // entry points are told so through a NEGATIVE scale argument
   VJ_OPT_BIAS_FUSE,            // 1 (default, round 4): qkv / fc1 bias gradients from column partials written by the kernels that
                                // PRODUCE dY (attention backward, fc2-dgrad epilogue), one reduction launch per block;
                                // 0: stand-alone column-sum kernels re-reading dY
@@ -34,6 +37,8 @@ enum VjOpt {
   VJ_OPT_GEMM_SCHED,           // load / compute section pairs per K-tile of the persistent NT GEMM: 8 = four pairs of 16 MFMAs (round 3),
                                // 4 = two pairs of 32 MFMAs (round 4: half the section boundaries); bit-identical results
   VJ_OPT_ATTN_PSUM,            // 1 (default): head_dim 24 forward takes its row sums from the V pad column (P.V MFMA); 0: vector adds
+  VJ_OPT_ATTN_MERGE,           // 1 (default): the chains launch attention ONCE per block for all segments (masks) of the batch
+                               // (vj_attn_fwd_segs / vj_attn_bwd_segs); 0: one launch (pair) per segment.  Bit-identical results
   VJ_OPT_COUNT
 };
 

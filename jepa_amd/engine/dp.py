@@ -12,10 +12,11 @@ mean inside the fused AdamW kernel (gscale = 1/world), so no extra pass touches 
 With world_size == 1 every method is a no-op.  On CPU tensors (gloo, used by the tests) the same bucket walk
 runs synchronously.
 
-Collective backend: torch.distributed's process group by default (backend "nccl" IS RCCL on ROCm; it is the group the
-launcher already created).  VJ_COMM_BACKEND=capi routes the bucket all-reduces through the library's own RCCL binding
-instead (`vj_comm_*`, include/vjepa_hip.h): same librccl, but no torch type on the path -- what a non-PyTorch host
-would call.  The 128-byte unique id still travels over the existing process group once, at construction.
+Collective contract: torch.distributed's process group (backend "nccl" IS RCCL on ROCm; it is the group the launcher already
+created).  The library also binds RCCL behind the C ABI (`vj_comm_*`, include/vjepa_hip.h) for hosts that do not run
+torch.distributed; this reducer does not use it: driven from here at one rank it made the step 17 % slower in rounds 3 and 4
+(91.0 vs 75.9 ms; the kernel trace shows no RCCL kernel, only inflated compute-kernel durations -- profiles/r04_dp1_capi_trace.md),
+so the switch that selected it (VJ_COMM_BACKEND) was removed in round 4.
 """
 import torch
 import torch.distributed as dist
@@ -35,7 +36,6 @@ class GradReducer:
         self._pending = []
         self.comm_stream = None
         self.launched = []     # (lo, hi) in launch order -- inspected by tests
-        self._capi = None      # vj_comm_t handle when VJ_COMM_BACKEND=capi
         self._exposed = []     # (event before, event after) the compute stream's wait on the collectives, per step
         self.exposed_samples = 0
         if not self.enabled:
@@ -67,25 +67,6 @@ class GradReducer:
             pos = max(pos, hi)
         if pos < total:
             self.tail.append((pos, total))
-        if os.environ.get("VJ_COMM_BACKEND", "torch") == "capi" and arena.G.is_cuda:
-            self._init_capi(arena.G.device)
-
-    def _init_capi(self, device):
-        """RCCL communicator through the C ABI: rank 0 draws the unique id, the process group broadcasts it."""
-        import ctypes
-        from ..hip.lib import check, load_library
-        lib = load_library()
-        n = lib.vj_comm_unique_id_bytes()
-        idt = torch.zeros(n, dtype=torch.uint8, device=device)
-        if dist.get_rank() == 0:
-            buf = (ctypes.c_ubyte * n)()
-            check(lib.vj_comm_unique_id(buf), "vj_comm_unique_id")
-            idt.copy_(torch.tensor(list(buf), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        raw = bytes(idt.cpu().tolist())
-        handle = ctypes.c_void_p()
-        check(lib.vj_comm_init(ctypes.byref(handle), dist.get_rank(), dist.get_world_size(), raw), "vj_comm_init")
-        self._capi = (lib, handle)
 
     def begin(self, producer_stream=None):
         """producer_stream: the HIP stream on which the per-layer weight gradients are enqueued (the engine's side
@@ -113,14 +94,8 @@ class GradReducer:
             self._ev_next = nxt + 1
             ev.record(producer if producer is not None else torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
-            if self._capi is not None:
-                from ..hip.lib import check
-                lib, handle = self._capi
-                check(lib.vj_comm_allreduce_bucket(handle, g.data_ptr(), g.numel(), self.comm_stream.cuda_stream),
-                      "vj_comm_allreduce_bucket")
-            else:
-                with torch.cuda.stream(self.comm_stream):
-                    self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+            with torch.cuda.stream(self.comm_stream):
+                self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
 

@@ -82,6 +82,17 @@ def _rows(t, seg):
     return t[seg.row0:seg.row0 + seg.rows]
 
 
+def _q_prescaled(D: int) -> bool:
+    from ..hip.lib import get_option
+    return get_option("attn_softmax") == 2 and D % 4 == 0
+
+
+def _f32_mul(a: float, b: float) -> float:
+    """a * b rounded as the C chain rounds it (float * float)."""
+    import numpy as np
+    return float(np.float32(np.float32(a) * np.float32(b)))
+
+
 # =============================================================================================== block
 def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
     """x [M, D] bf16 -> x2 [M, D]; returns (x2, saved)."""
@@ -89,7 +100,11 @@ def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
     hd = D // heads
     scale = hd ** -0.5
     y1, mean1, rstd1 = ops.layernorm_fwd(x, bw.norm1.g, bw.norm1.b, LN_EPS, save_stats=save)
-    qkv = ops.gemm_nt(y1, bw.qkv.w, bias=bw.qkv.b)
+    if _q_prescaled(D):   # option attn_softmax = 2 (as vj_blocks_fwd): the q third of qkv carries scale * log2(e)
+        qkv = ops.gemm_nt(y1, bw.qkv.w, bias=bw.qkv.b, epilogue=ops.EPI_QKV, alpha=_f32_mul(scale, 1.4426950408889634))
+        scale = -scale    # "q is pre-scaled" for the attention entry points
+    else:
+        qkv = ops.gemm_nt(y1, bw.qkv.w, bias=bw.qkv.b)
     o = torch.empty_like(x)
     lses = []
     for sg in segs:
@@ -184,6 +199,8 @@ def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: f
     D = x.shape[1]
     hd = D // heads
     scale = hd ** -0.5
+    if _q_prescaled(D):
+        scale = -scale       # the forward stored q pre-scaled (option attn_softmax = 2)
     acc = beta != 0.0
     fuse = _tn_ok(8, 8)
     defer = [] if _group_ok(bw) else None

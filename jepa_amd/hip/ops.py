@@ -15,6 +15,7 @@ F32 = torch.float32
 I64 = torch.int64
 
 EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32 = 0, 1, 2, 3
+EPI_QKV = 4   # EPI_BF16 whose first N/3 output columns (the q part of a qkv projection) are multiplied by alpha before the rounding
 
 
 _raw_stream = torch._C._cuda_getCurrentRawStream   # C accessor: ~20x cheaper than torch.cuda.current_stream()
@@ -333,6 +334,50 @@ def attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
     if _ev is not None:
         _ev.record()
     return dqkv
+
+
+def _seg_array(segs):
+    from .lib import VjSeg
+    arr = (VjSeg * len(segs))()
+    for i, (row0, B, S) in enumerate(segs):
+        arr[i] = VjSeg(row0, B, S)
+    return arr
+
+
+def attn_fwd_segs(qkv, segs, H, hd, scale, save_lse=True, stream=None):
+    """Attention over several [B_i, S_i] segments of one activation in ONE launch (vj_attn_fwd_segs).  qkv [M, 3*H*hd] bf16;
+    segs: list of (row0, B, S) -> o [M, H*hd], lse2 flat [H*M] (segment i: [B_i, H, S_i] at H*row0_i)."""
+    lib = load_library()
+    _req(qkv, BF16, "qkv")
+    M = qkv.shape[0]
+    o = torch.empty((M, H * hd), dtype=BF16, device=qkv.device)
+    lse = torch.empty((H * M,), dtype=F32, device=qkv.device) if save_lse else None
+    check(lib.vj_attn_fwd_segs(_ptr(qkv), _ptr(o), _ptr(lse), _seg_array(segs), len(segs), H, hd, scale, _stream(stream)),
+          "vj_attn_fwd_segs")
+    return o, lse
+
+
+def attn_bwd_segs(qkv, o, dout, lse, segs, H, hd, scale, colsum=False, stream=None):
+    """Backward of attn_fwd_segs in one launch pair (vj_attn_bwd_segs) -> dqkv [, colq, colkv: the segments' column partials one
+    after the other]."""
+    import ctypes
+    lib = load_library()
+    _req(dout, BF16, "dout")
+    M = qkv.shape[0]
+    dqkv = torch.empty_like(qkv)
+    ws = Scratch.get(4 * H * M, qkv.device, "attn", stream=stream)
+    colq = colkv = None
+    if colsum:
+        rq_t = rkv_t = 0
+        for _, B, S in segs:
+            rq, rkv = ctypes.c_int64(0), ctypes.c_int64(0)
+            check(lib.vj_attn_bwd_colsum_rows(B, S, hd, ctypes.byref(rq), ctypes.byref(rkv)), "vj_attn_bwd_colsum_rows")
+            rq_t, rkv_t = rq_t + (rq.value if B * S else 0), rkv_t + (rkv.value if B * S else 0)
+        colq = torch.empty((rq_t, H * hd), dtype=F32, device=qkv.device)
+        colkv = torch.empty((rkv_t, 2 * H * hd), dtype=F32, device=qkv.device)
+    check(lib.vj_attn_bwd_segs(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), _seg_array(segs), len(segs), H, hd, scale,
+                               _ptr(ws), 4 * H * M, _ptr(colq), _ptr(colkv), _stream(stream)), "vj_attn_bwd_segs")
+    return (dqkv, colq, colkv) if colsum else dqkv
 
 
 def attn_bwd_colsum(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):

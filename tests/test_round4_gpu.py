@@ -127,6 +127,20 @@ def test_seeded_softmax_rebase_paths(ops, hd):
         assert float(err.max()) < bound, (sm, float(err.max()))
         if sm == 1:
             e_sm1 = float(err.max())
+    # the same rows with the scale applied to q ONCE, before its only rounding (what the qkv GEMM epilogue does under option
+    # attn_softmax = 2): the seeded kernels are then as exact as the round-3 ones -- forward 3e-2
+    c = hd ** -0.5 * math.log2(math.e)
+    tq = t.clone()
+    tq[:, :, 0] = tq[:, :, 0] * c
+    pre = bf(tq.reshape(B * S, -1)).to(DEV)
+    xr = pre.float().view(B * S, 3, H * hd).clone()
+    xr[:, 0] = xr[:, 0] / c
+    ref_pre = sdpa_ref(xr.view(B * S, -1), B, S, H, hd)
+    with _opt("attn_softmax", 1):
+        o_p, _ = ops.attn_fwd(pre, B, S, H, hd, -(hd ** -0.5))
+    e_p = float((o_p.float() - ref_pre).abs().max())
+    print(f"adversarial rows hd={hd}, q pre-scaled before its rounding: forward max abs error {e_p:.3e}")
+    assert e_p < 3e-2, e_p
     if hd == 24:   # the same rows with the row sums on the vector pipe: the pad-column sums must not be the less accurate ones
         with _opt("attn_softmax", 1), _opt("attn_psum", 0):
             o_v, _ = ops.attn_fwd(qkv, B, S, H, hd, hd ** -0.5)
@@ -145,6 +159,127 @@ def test_seeded_softmax_rebase_paths(ops, hd):
         e = rel_l2(dqkv, x.grad)
         print(f"adversarial rows hd={hd} attn_softmax={sm}: backward rel-L2 {e:.2e}")
         assert e < bound, (sm, e)
+
+
+# ------------------------------------------------------------------------------------------ soft-max scale applied by the qkv GEMM
+LOG2E = 1.4426950408889634
+
+
+@pytest.mark.parametrize("M,D,K", [(10560, 1024, 1024), (4000, 384, 384), (300, 192, 192), (2049, 1280, 1280)])
+def test_qkv_gemm_epilogue_scales_the_q_columns_before_rounding(ops, M, D, K):
+    """vj_gemm_bf16_nt epilogue 4: out[:, :N/3] = bf16((acc + bias) * alpha), the other two thirds bit-identical to epilogue 0;
+    the q third within bf16 rounding of the fp32 product (rel-L2 4e-3).  Persistent kernel, one-tile kernel and the small generic
+    kernel (M = 300) all take the column scale."""
+    g = torch.Generator().manual_seed(81)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(3 * D, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(3 * D, generator=g).to(DEV)
+    c = 0.125 * LOG2E
+    plain = ops.gemm_nt(A, W, bias=bias)
+    got = ops.gemm_nt(A, W, bias=bias, epilogue=ops.EPI_QKV, alpha=c)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, D:], plain[:, D:])
+    ref_q = (A.float() @ W[:D].float().t() + bias[:D]) * c
+    assert rel_l2(got[:, :D], ref_q) < 4e-3, rel_l2(got[:, :D], ref_q)
+    # one rounding: the scaled q is NOT the re-rounded plain q (which is what scaling inside the attention kernels gives)
+    twice = (plain[:, :D].float() * c).to(torch.bfloat16)
+    assert rel_l2(got[:, :D], ref_q) <= rel_l2(twice, ref_q) + 1e-6
+
+
+@pytest.mark.parametrize("B,S,H,hd", [(2, 366, 16, 64), (1, 1568, 4, 64), (2, 1113, 4, 24), (1, 65, 2, 24), (2, 200, 2, 80),
+                                      (1, 129, 2, 128), (3, 52, 3, 32)])
+def test_attention_with_prescaled_q(ops, B, S, H, hd):
+    """scale < 0 = "the q part already carries |scale| * log2(e)" (what the chains do with option attn_softmax = 2): forward and
+    backward against fp32 SDPA on the SAME operands (q_ref = q' / c), the round-3 bounds (8e-3 / 1.5e-2); dq is the gradient of
+    the UNscaled q (what the qkv dgrad / wgrad consume)."""
+    g = torch.Generator().manual_seed(91)
+    qkv = bf(torch.randn(B * S, 3 * H * hd, generator=g))
+    dout = bf(torch.randn(B * S, H * hd, generator=g)).to(DEV)
+    scale = hd ** -0.5
+    c = scale * LOG2E
+    pre = qkv.clone().view(B * S, 3, H * hd)
+    pre[:, 0] = (pre[:, 0].float() * c).to(torch.bfloat16)          # stored q' (here from the rounded q: any bf16 values will do)
+    pre = pre.view(B * S, -1).to(DEV)
+    xr = pre.float().view(B * S, 3, H * hd).clone()
+    xr[:, 0] = xr[:, 0] / c                                          # the q the stored q' stands for
+    xr = xr.view(B * S, -1).requires_grad_(True)
+    o_ref = sdpa_ref(xr, B, S, H, hd)
+    o_ref.backward(dout.float())
+    for sm in (1, 0):                                                # the seeded kernels and the round-3 kernels both accept it
+        with _opt("attn_softmax", sm):
+            o, lse = ops.attn_fwd(pre, B, S, H, hd, -scale)
+            dqkv = ops.attn_bwd(pre, o, dout, lse, B, S, H, hd, -scale)
+            torch.cuda.synchronize()
+        e = rel_l2(o, o_ref)
+        assert e < 8e-3, ("fwd", sm, e)
+        gref, gout = xr.grad.view(B, S, 3, H, hd), dqkv.float().view(B, S, 3, H, hd)
+        errs = [rel_l2(gout[:, :, i], gref[:, :, i]) for i in range(3)]
+        print(f"prescaled q, attn_softmax={sm}, B{B} S{S} H{H} hd{hd}: o {e:.2e} dq {errs[0]:.2e} dk {errs[1]:.2e} dv {errs[2]:.2e}")
+        assert max(errs) < 1.5e-2, (sm, errs)
+
+
+def test_block_chain_with_the_scale_in_the_qkv_gemm():
+    """Option attn_softmax = 2 in the block chains (qkv GEMM epilogue 4 + attention told "q is pre-scaled"): the C chain and the
+    per-kernel Python chain stay bit-identical, and the step agrees with option 1 (scale folded inside the attention kernels) to
+    bf16 noise: loss 2e-4 relative, gradient arena 2e-2 rel-L2."""
+    from jepa_amd.engine import layers
+    tr, _, _, _, _ = build_trainer(TINY, 2, perturb_small=True)
+    clips, me, mp = draw_batch(_gens(), 4, TINY, 71, 72)
+    cd, med, mpd = to_dev(clips, me, mp)
+    res = {}
+    with _opt("bias_fuse", 0):
+        for key, (sm, c_chain) in {"c2": (2, True), "py2": (2, False), "c1": (1, True)}.items():
+            layers.USE_C_CHAIN = c_chain
+            try:
+                with _opt("attn_softmax", sm):
+                    o = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
+                    torch.cuda.synchronize()
+                res[key] = (o.loss, tr.arena.G.clone())
+            finally:
+                layers.USE_C_CHAIN = True
+    assert res["c2"][0] == res["py2"][0] and torch.equal(res["c2"][1], res["py2"][1])
+    assert abs(res["c2"][0] - res["c1"][0]) <= 2e-4 * abs(res["c1"][0]), (res["c2"][0], res["c1"][0])
+    r = rel_l2(res["c2"][1].cpu(), res["c1"][1].cpu())
+    assert r < 2e-2, r
+
+
+# ------------------------------------------------------------------------------------------ several segments, one launch
+@pytest.mark.parametrize("H,hd,shapes", [(16, 64, [(3, 366), (3, 107)]), (16, 24, [(2, 1113), (2, 1208)]), (3, 32, [(2, 52), (0, 7), (2, 20)]),
+                                         (2, 80, [(2, 200), (1, 63), (3, 129), (1, 16)]), (2, 128, [(1, 129), (2, 64)])])
+@pytest.mark.parametrize("sm", [0, 1])
+def test_attention_over_several_segments_in_one_launch(ops, H, hd, shapes, sm):
+    """vj_attn_fwd_segs / vj_attn_bwd_segs (the masks of a batch concatenated along the rows, one launch for all of them) must give
+    the bits of one vj_attn_fwd / vj_attn_bwd call per segment: o, lse2, dqkv and the column partials (segment after segment).
+    Includes an empty segment and the 4-segment maximum."""
+    g = torch.Generator().manual_seed(77)
+    segs, r = [], 0
+    for B, S in shapes:
+        segs.append((r, B, S))
+        r += B * S
+    M = r
+    qkv = bf(torch.randn(M, 3 * H * hd, generator=g)).to(DEV)
+    dout = bf(torch.randn(M, H * hd, generator=g)).to(DEV)
+    scale = hd ** -0.5
+    with _opt("attn_softmax", sm):
+        o, lse = ops.attn_fwd_segs(qkv, segs, H, hd, scale)
+        dqkv, colq, colkv = ops.attn_bwd_segs(qkv, o, dout, lse, segs, H, hd, scale, colsum=True)
+        dq2 = ops.attn_bwd_segs(qkv, o, dout, lse, segs, H, hd, scale)
+        torch.cuda.synchronize()
+        assert torch.equal(dq2, dqkv)
+        oq = okv = 0
+        for row0, B, S in segs:
+            if B * S == 0:
+                continue
+            sl = slice(row0, row0 + B * S)
+            o1, lse1 = ops.attn_fwd(qkv[sl], B, S, H, hd, scale)
+            d1, cq1, ckv1 = ops.attn_bwd_colsum(qkv[sl], o1, dout[sl], lse1, B, S, H, hd, scale)
+            torch.cuda.synchronize()
+            assert torch.equal(o[sl], o1), (row0, "o")
+            assert torch.equal(lse[H * row0:H * (row0 + B * S)].view(B, H, S), lse1), (row0, "lse")
+            assert torch.equal(dqkv[sl], d1), (row0, "dqkv")
+            assert torch.equal(colq[oq:oq + cq1.shape[0]], cq1) and torch.equal(colkv[okv:okv + ckv1.shape[0]], ckv1), (row0, "partials")
+            oq, okv = oq + cq1.shape[0], okv + ckv1.shape[0]
+        assert oq == colq.shape[0] and okv == colkv.shape[0]
 
 
 # ------------------------------------------------------------------------------------------ bias-gradient column partials
