@@ -488,7 +488,10 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __r
 // =============================================================================================================
 // forward, round 4 ("seeded" soft-max, see SM_HEADROOM above): same tiling, staging and MFMA layout as attn_fwd_kernel
 // =============================================================================================================
-template <int HDP, int QT, int NBUF, bool PSUM>
+// RS = where the soft-max row sums come from: 0 vector adds (v_pk_add_f32 on the fp32 probabilities), 1 the V pad column (head_dim 24),
+// 2 an all-ones A operand: two extra P MFMAs per key tile and 16-row block put sum_k bf16(P) in every row of a 16 x 16 accumulator --
+// packed f32 adds next to MFMAs cost twice their stand-alone time (profiles/r03_valu_mfma_probe.md), the two MFMAs 32 cycles
+template <int HDP, int QT, int NBUF, int RS>
 __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* __restrict__ qkv_all,
                                                           bf16_t* __restrict__ o_all, float* __restrict__ lse2_all,
                                                           AttnSegs sg, int H, int hd, float sc) {
@@ -496,6 +499,7 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
   using RT = RowTile<HDP, NT>;
   constexpr int DIST = NBUF - 1;
   static_assert(RT::CAN_FULL || NT == 512, "tile items must be a multiple of the workgroup size");
+  constexpr bool PSUM = RS == 1;
   static_assert(!PSUM || (HDP == 32 && RT::CAN_FULL && RT::NIT == 1), "row sums on the pad column: 32-wide class, one DMA item per thread");
   constexpr int NDMA = RT::CAN_FULL ? RT::NIT : 1;
   __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * RT::BYTES];
@@ -533,11 +537,13 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
     for (int dt = 0; dt < DT; dt++) oacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   // mrun: the base the scores are measured against (s - mrun comes out of the matrix pipe); 0 until the first tile set it
   float mrun[QT], lrun[QT];
+  f32x4_t lacc[QT];            // RS = 2: row sums out of the matrix pipe (every row of the block holds sum_k P[q = li][k])
   f32x4_t seed[QT];            // {-mrun} x 4: srcC of the first score MFMA of every key tile
 #pragma unroll
   for (int qt = 0; qt < QT; qt++) {
     mrun[qt] = 0.f;
     lrun[qt] = 0.f;
+    lacc[qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     seed[qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
 
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
           for (int hf = 0; hf < 2; hf++) {
             const int kt = 2 * c + k2;
             const f32x2_t e = {__builtin_amdgcn_exp2f(sacc[qt][kt][2 * hf]), __builtin_amdgcn_exp2f(sacc[qt][kt][2 * hf + 1])};
-            if constexpr (!PSUM) ls2[qt] += e;
+            if constexpr (RS == 0) ls2[qt] += e;
             pw[qt][c][2 * k2 + hf] = cvt_pk_bf16(e[0], e[1]);
           }
     };
@@ -681,6 +687,7 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
           shift = fmaxf(shift, 0.f);
           const float alpha = __builtin_amdgcn_exp2f(-shift);
           lrun[qt] *= alpha;
+          if constexpr (RS == 2) lacc[qt] *= alpha;
 #pragma unroll
           for (int dt = 0; dt < DT; dt++) oacc[qt][dt] *= alpha;
         }
@@ -694,7 +701,7 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
     bf16x8_t pf[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
-      if constexpr (!PSUM) lrun[qt] += ls2[qt][0] + ls2[qt][1];
+      if constexpr (RS == 0) lrun[qt] += ls2[qt][0] + ls2[qt][1];
       pf[qt][0] = __builtin_bit_cast(bf16x8_t, pw[qt][0]);
       pf[qt][1] = __builtin_bit_cast(bf16x8_t, pw[qt][1]);
     }
@@ -708,6 +715,14 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
         for (int qt = 0; qt < QT; qt++)
           oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
       }
+    if constexpr (RS == 2) {
+      const u32x4_t one4 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+      const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, one4);
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qt][c], lacc[qt], 0, 0, 0);
+    }
   };
   const int nfull = RT::CAN_FULL ? S / 64 : 0;
   const int t_fast = nfull - DIST > 0 ? nfull - DIST : 0;
@@ -723,6 +738,8 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
     if constexpr (PSUM) {
       // column hd = 24 of O^T: tile dt = 1, rows 4g + r = 8 -> lanes g == 2, element 0; broadcast to the row's four lane groups
       l = __shfl(oacc[qt][1][0], 32 + li, 64);
+    } else if constexpr (RS == 2) {
+      l = lacc[qt][0];   // every row of the block holds the sum of column q = li
     } else {
       l = lrun[qt];
       l += __shfl_xor(l, 16, 64);
@@ -1280,17 +1297,19 @@ extern "C" int vj_attn_fwd_segs(const void* qkv, void* o, float* lse2, const vj_
   // of vj_gemm_bf16_nt): the kernels' own factor becomes 1 (scale_frag(x, 1) is the identity)
   const float sc = scale < 0.f ? 1.0f : scale * LOG2E;
   // round-4 kernels (seeded soft-max); head_dim 24: row sums on the pad column
-#define VJ_FWD_SM(HDPV, NB, PS)                                                                                       \
-  hipLaunchKernelGGL((attn_fwd_sm_kernel<HDPV, 2, NB, PS>), dim3((unsigned)nblk), dim3(256), 0, stream,                \
+#define VJ_FWD_SM(HDPV, NB, RSV)                                                                                      \
+  hipLaunchKernelGGL((attn_fwd_sm_kernel<HDPV, 2, NB, RSV>), dim3((unsigned)nblk), dim3(256), 0, stream,               \
                      (const bf16_t*)qkv, (bf16_t*)o, lse2, sg, (int)H, (int)hd, sc)
+  const int psum = vj_opt(VJ_OPT_ATTN_PSUM);   // 0: row sums on the vector pipe; 1: pad column (hd 24) / ones-operand MFMA (others)
   switch (pick_hdp(hd)) {
     case 32:
-      if (hd == 24 && vj_opt(VJ_OPT_ATTN_PSUM) != 0) VJ_FWD_SM(32, 3, true);
-      else VJ_FWD_SM(32, 3, false);
+      if (hd == 24 && psum != 0) VJ_FWD_SM(32, 3, 1);
+      else if (psum != 0) VJ_FWD_SM(32, 3, 2);
+      else VJ_FWD_SM(32, 3, 0);
       break;
-    case 64: VJ_FWD_SM(64, 2, false); break;
-    case 96: VJ_FWD_SM(96, 2, false); break;
-    default: VJ_FWD_SM(128, 2, false);
+    case 64: if (psum != 0) VJ_FWD_SM(64, 2, 2); else VJ_FWD_SM(64, 2, 0); break;
+    case 96: if (psum != 0) VJ_FWD_SM(96, 2, 2); else VJ_FWD_SM(96, 2, 0); break;
+    default: if (psum != 0) VJ_FWD_SM(128, 2, 2); else VJ_FWD_SM(128, 2, 0);
   }
 #undef VJ_FWD_SM
   VJ_LAUNCH_CHECK("vj_attn_fwd");

@@ -36,7 +36,8 @@ enum VjOpt {
                                // v_exp); 0: Abramowitz-Stegun 7.1.26
   VJ_OPT_GEMM_SCHED,           // load / compute section pairs per K-tile of the persistent NT GEMM: 8 = four pairs of 16 MFMAs (round 3),
                                // 4 = two pairs of 32 MFMAs (round 4: half the section boundaries); bit-identical results
-  VJ_OPT_ATTN_PSUM,            // 1 (default): head_dim 24 forward takes its row sums from the V pad column (P.V MFMA); 0: vector adds
+  VJ_OPT_ATTN_PSUM,            // 1 (default): the forward takes its soft-max row sums from the matrix pipe (head_dim 24: the V pad column of
+                               // the P.V MFMA; other head sizes: an all-ones operand, two extra MFMAs per key tile); 0: vector adds
   VJ_OPT_ATTN_MERGE,           // 1 (default): the chains launch attention ONCE per block for all segments (masks) of the batch
                                // (vj_attn_fwd_segs / vj_attn_bwd_segs); 0: one launch (pair) per segment.  Bit-identical results
   VJ_OPT_COUNT

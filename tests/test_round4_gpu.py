@@ -446,3 +446,34 @@ def test_block_chain_bias_fuse_vitl_b24_and_micro_batches():
     assert abs(lm - l1) <= 1e-6 * abs(l1)
     r = float((gm.double() - g1.double()).norm() / g1.double().norm())
     assert r < 2e-5, r
+
+
+# ------------------------------------------------------------------------------------------ configs[3]: ViT-H in micro-batches of 24
+@pytest.mark.timeout(1200)
+def test_vith_micro_batches_of_24_reproduce_the_full_batch():
+    """BASELINE configs[3] runs ViT-H/16 with 384 clips per GPU walked 24 at a time (bench.py --workload vith16).  The same
+    structure at a size a single pass can still hold: B = 48 as one batch against two micro-batches of 24 (gradient
+    accumulation through beta = 1 in every gradient writer, incl. the fused bias partials and the one reduction launch per block;
+    losses accumulated on the device with the whole-batch normalisation).  lr = wd = 0, ema = 1: identical weights for both runs.
+    Loss equal to 1e-6 relative, gradient arena rel-L2 <= 2e-5 (fp32 sums in a different order), every gradient finite."""
+    from oracle import vjepa_oracle as O
+    from tests.step_util import VITH, VITL_MASKS
+    tr, _, _, _, _ = build_trainer(VITH, 2)
+    gens = O.make_mask_gens(VITL_MASKS, VITH["crop"], VITH["frames"], VITH["patch"], VITH["tubelet"])
+    clips, me, mp = draw_batch(gens, 48, VITH, 2024, 2025)
+    cd, med, mpd = to_dev(clips, me, mp)
+    out = {}
+    for mb in (None, 24):
+        tr.micro_batch = mb
+        try:
+            o = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
+            torch.cuda.synchronize()
+            out[mb] = (o.loss, tr.arena.G.clone(), o.skipped)
+        finally:
+            tr.micro_batch = None
+    (l0, g0, sk0), (l1, g1, sk1) = out[None], out[24]
+    assert not sk0 and not sk1 and bool(torch.isfinite(g0).all()) and bool(torch.isfinite(g1).all())
+    assert abs(l1 - l0) <= 1e-6 * abs(l0), (l1, l0)
+    r = float((g1.double() - g0.double()).norm() / g0.double().norm())
+    print(f"ViT-H B=48: one batch vs 2 x 24: loss {l0:.6f} / {l1:.6f}, gradient arena rel-L2 {r:.2e}")
+    assert r < 2e-5, r
