@@ -129,7 +129,7 @@ extern "C" int vj_prof_collect(double* ms, double* flop, int64_t* launches, cons
     launches[i] = 0;
   }
   FILE* f = csv_path && csv_path[0] ? fopen(csv_path, "w") : nullptr;
-  if (f) fprintf(f, "family,tag,m,n,k,us\n");
+  if (f) fprintf(f, "family,tag,m,n,k,us,flop\n");
   for (auto& r : g_prof) {
     float t = 0.f;
     HIPCH(hipEventSynchronize(r.e), "vj_prof_collect");
@@ -137,7 +137,7 @@ extern "C" int vj_prof_collect(double* ms, double* flop, int64_t* launches, cons
     ms[r.family] += t;
     flop[r.family] += r.flop;
     launches[r.family] += 1;
-    if (f) fprintf(f, "%d,%d,%ld,%ld,%ld,%.3f\n", r.family, r.tag, (long)r.m, (long)r.n, (long)r.k, 1e3 * t);
+    if (f) fprintf(f, "%d,%d,%ld,%ld,%ld,%.3f,%.6e\n", r.family, r.tag, (long)r.m, (long)r.n, (long)r.k, 1e3 * t, r.flop);
     (void)hipEventDestroy(r.s);
     (void)hipEventDestroy(r.e);
   }

@@ -289,7 +289,10 @@ def _dp_worker(rank, world, port, q):
         if rank == 0:
             for name in ("blocks.3.mlp.fc1.weight", "blocks.11.attn.proj.weight"):
                 w = tr.arena.f32("enc." + name).cpu()
-                assert (w - state["enc"][name]).abs().max() <= 2.5 * lr + 1e-7
+                # per element: Adam moves a weight by at most ~lr per step whatever the size of its gradient, in the direction of
+                # its SIGN -- an element whose gradient is bf16 noise around zero may take the other direction than the oracle's in
+                # both steps: 2 * (lr_1 + lr_2) <= 4 * lr_2 apart at worst.  The tensor as a whole: 2e-3 rel-L2.
+                assert (w - state["enc"][name]).abs().max() <= 4.0 * lr + 1e-7
                 assert rel_l2(w, state["enc"][name]) < 2e-3
             assert len(tr.reducer.launched) == len(tr.reducer.buckets) + len(tr.reducer.tail)
         dist.barrier()
@@ -306,7 +309,7 @@ def test_two_rank_step_on_one_gpu_matches_oracle_with_averaged_gradients():
     """DDP numerics (train.py:295-297) before an 8-GPU box exists: two processes on cuda:0, gloo backend, different
     clips and different mask sizes per rank; the bucketed reducer runs its real hook / stream / event path.  Gradients
     (arena SUM / world) vs the oracle's rank-averaged gradients: rel-L2 <= 6e-2 (TINY model); weights equal across ranks bit for bit
-    and within 2.5*lr of the oracle's."""
+    and within 4*lr of the oracle's per element, 2e-3 rel-L2 per tensor."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
