@@ -133,6 +133,61 @@ __device__ __forceinline__ void gelu_dgelu2(f32x2_t x, f32x2_t& y, f32x2_t& d) {
   const f32x2_t c = {0.3989422804014327f, 0.3989422804014327f};
   d = __builtin_elementwise_fma(x * c, g, phi);                                    // = dgelu2(x), bit for bit
 }
+// ---- round 4: q = Phi(-|x|) without the reciprocal (option gelu_poly, default) --------------------------------------------
+// log2 Phi(-a) is a smooth, nearly quadratic function of a >= 0 (-1 at 0, ~ -a^2 log2(e)/2 - log2(a sqrt(2 pi)) far out), so
+// q(a) = exp2(L(a)) with a degree-6 minimax polynomial L on [0, 5] (Lawson iteration, max |dL| 1.8e-5, i.e. q to 1.3e-5
+// RELATIVE over the whole range, tail included) replaces A-S 7.1.26's v_rcp + 4 FMAs + 3 multiplies by 6 FMAs; the one v_exp
+// stays.  a = min(|x|, 5) is ONE instruction (v_min_f32 with the |x| source modifier) and is used for the product a * q as
+// well: beyond 5 the result is relu(x) - 5 q(5) = relu(x) - 1.4e-6 (exact: relu(x) - |x| Phi(-|x|), at most 1.4e-6 there).
+// Against the correctly rounded bf16 erf-GELU over ALL finite bf16 inputs x > -5: 5 of 20712 results differ (by one bf16 ulp);
+// the A-S form: 22 (tests/test_gelu_poly.py enumerates them on the CPU with this arithmetic).  relu(x) is taken as
+// 0.5 * (x + |x|): exact for finite x, and a NaN of EITHER sign propagates (relu_bits drops a negative-signed NaN, which
+// the A-S form only survives because its reciprocal carries the NaN into q).
+// x + |x| = 2 relu(x) as ONE v_add_f32 with the |x| source modifier (hipcc turns the C expression into v_and + a packed add);
+// exact for |x| < 2^127 (no cancellation error for negative x, unlike 0.5 x + 0.5 |x| - ...), +inf above; a NaN of either sign stays a NaN
+__device__ __forceinline__ float twice_relu(float x) {
+  float s;
+  asm("v_add_f32 %0, %1, |%1|" : "=v"(s) : "v"(x));
+  return s;
+}
+__device__ __forceinline__ f32x2_t half_erfc2_lp(f32x2_t x, f32x2_t& a) {
+  // v_med3_f32 a, |x|, 0, 5: one instruction (fminf(fabsf(x), 5) costs a canonicalising v_max + v_min + v_and)
+  a = (f32x2_t){__builtin_amdgcn_fmed3f(__builtin_fabsf(x[0]), 0.0f, 5.0f), __builtin_amdgcn_fmed3f(__builtin_fabsf(x[1]), 0.0f, 5.0f)};
+  const f32x2_t c6 = {2.945814386e-05f, 2.945814386e-05f}, c5 = {-7.087827263e-04f, -7.087827263e-04f},
+                 c4 = {7.746013931e-03f, 7.746013931e-03f}, c3 = {-5.260629358e-02f, -5.260629358e-02f},
+                 c2 = {-4.596254594e-01f, -4.596254594e-01f}, c1 = {-1.150867238e+00f, -1.150867238e+00f},
+                 c0 = {-1.000017643e+00f, -1.000017643e+00f};
+  f32x2_t p = __builtin_elementwise_fma(c6, a, c5);
+  p = __builtin_elementwise_fma(p, a, c4);
+  p = __builtin_elementwise_fma(p, a, c3);
+  p = __builtin_elementwise_fma(p, a, c2);
+  p = __builtin_elementwise_fma(p, a, c1);
+  p = __builtin_elementwise_fma(p, a, c0);
+  return (f32x2_t){__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+}
+// gelu(x) = relu(x) - a q(a)
+__device__ __forceinline__ f32x2_t gelu2_lp(f32x2_t x) {
+  f32x2_t a;
+  const f32x2_t q = half_erfc2_lp(x, a);
+  const f32x2_t s = {twice_relu(x[0]), twice_relu(x[1])};
+  const f32x2_t half = {0.5f, 0.5f};
+  return __builtin_elementwise_fma(s, half, -(a * q));
+}
+// gelu(x) and gelu'(x) = Phi(x) + x pdf(x): Phi from the same q, the Gaussian term from its own v_exp
+__device__ __forceinline__ void gelu_dgelu2_lp(f32x2_t x, f32x2_t& y, f32x2_t& d) {
+  f32x2_t a;
+  const f32x2_t q = half_erfc2_lp(x, a);
+  const f32x2_t s = {twice_relu(x[0]), twice_relu(x[1])};
+  const f32x2_t half = {0.5f, 0.5f};
+  y = __builtin_elementwise_fma(s, half, -(a * q));                                  // = gelu2_lp(x), bit for bit
+  const f32x2_t c = {-0.72134752044448170f, -0.72134752044448170f};                  // -0.5 * log2(e)
+  const f32x2_t e = (x * c) * x;
+  const f32x2_t g = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};    // exp(-x^2/2)
+  const f32x2_t hq = half - q;
+  const f32x2_t phi = half + (f32x2_t){copysignf(hq[0], x[0]), copysignf(hq[1], x[1])};
+  const f32x2_t k = {0.3989422804014327f, 0.3989422804014327f};
+  d = __builtin_elementwise_fma(x * k, g, phi);
+}
 // gelu'(x) = Phi(x) + x * pdf(x),  Phi(x) = 0.5 + copysign(0.5 - q, x)
 __device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {
   f32x2_t q, g;

@@ -25,6 +25,7 @@ struct GemmArgs {
   int64_t qcols;       //   of a qkv projection carries the soft-max scale scale*log2(e): ONE rounding of c*q, attention.hip); qcols % 4 == 0
   float* colpart;      // EPI_DGELU on the persistent kernel, nullable: fp32 column-sum partials of the OUTPUT, [2 * tiles_m][N]
                        // (row slot = 2 * row tile + wave row): the bias gradient of the Linear whose dY this GEMM produces
+  int gelu_lp;         // EPI_GELU: != 0 -> Phi(-|x|) = exp2(degree-6 polynomial) (common.hpp, option gelu_poly); 0 -> A-S 7.1.26
 };
 
 
@@ -38,7 +39,7 @@ struct GemmArgs {
 // nullable operands are resolved once by the caller-side variant switch (HAS_OPT), the bias is complete before the
 // first row (one explicit wait), and the row operands (residual / saved pre-activation) are fetched one row-block ahead
 // so that a row's stores stay in flight while the next row is computed.
-template <int EPI, int FM, int FN, bool HAS_OPT, bool EDGE, bool BETA = false, bool QS = false>
+template <int EPI, int FM, int FN, bool HAS_OPT, bool EDGE, bool BETA = false, bool QS = false, bool LP = false>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int64_t m_base,
                                                    int64_t n_base, int frow, int fg, int slice) {
   static_assert(!QS || (EPI == EPI_BF16 && !HAS_OPT), "column scale: the qkv projection (bf16 output, no residual)");
@@ -139,12 +140,20 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
           // GELU (and, for a layer that will run backward, gelu') of the bf16-ROUNDED pre-activation
           if constexpr (HAS_OPT) {
             f32x2_t d01, d23;
-            gelu_dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
-            gelu_dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
+            if constexpr (LP) {
+              gelu_dgelu2_lp((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
+              gelu_dgelu2_lp((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
+            } else {
+              gelu_dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
+              gelu_dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
+            }
             u32x2_t dw;
             dw[0] = pack_bf2(d01[0], d01[1]);
             dw[1] = pack_bf2(d23[0], d23[1]);
             if (mok && cok[j]) *(u32x2_t*)(auxo + ncl[j]) = dw;
+          } else if constexpr (LP) {
+            v01 = gelu2_lp((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+            v23 = gelu2_lp((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
           } else {
             v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
             v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
@@ -178,7 +187,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 // rows below `row_lo` -- the part of a SHIFTED edge tile that belongs to its neighbour -- are left out) and writes the 64
 // column sums to p.colpart[slot][n_base ..]: du = dY of fc1 is produced here, so fc1's bias gradient costs 64 packed FMAs + 64
 // DPP adds per wave tile instead of a second pass over du (colsum_bf16_kernel: 84 MB per ViT-L context block).
-template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false>
+template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage,
                                                      int64_t row_lo = 0, int slot = 0) {
@@ -291,12 +300,20 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
           // GELU (and, for a layer that will run backward, gelu') of the bf16-ROUNDED pre-activation
           if constexpr (TWO_OUT) {
             f32x2_t d01, d23;
-            gelu_dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
-            gelu_dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
+            if constexpr (LP) {
+              gelu_dgelu2_lp((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
+              gelu_dgelu2_lp((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
+            } else {
+              gelu_dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
+              gelu_dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
+            }
             u32x2_t dw;
             dw[0] = pack_bf2(d01[0], d01[1]);
             dw[1] = pack_bf2(d23[0], d23[1]);
             *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = dw;   // the saved derivative: stage blocks 0 .. RPP-1
+          } else if constexpr (LP) {
+            v01 = gelu2_lp((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
+            v23 = gelu2_lp((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
           } else {
             v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
             v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
@@ -372,6 +389,18 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
         return true;
       }
     }
+    if constexpr (EPI == EPI_GELU) {
+      if (p.gelu_lp) {   // workgroup-uniform (kernel argument)
+        if (opt) {
+          if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        } else {
+          if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        }
+        return true;
+      }
+    }
     if (opt) {
       if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
       else gemm_epilogue_staged<EPI, true, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
@@ -398,6 +427,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
     if (p.qscale != 0.f && n_base < p.qcols) {   // wave tiles that hold q columns only (the launcher guarantees: no residual)
       if (edge) gemm_epilogue_impl<EPI, FM, FN, false, true, false, true>(p, acc, m_base, n_base, frow, fg, slice);
       else gemm_epilogue_impl<EPI, FM, FN, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      return;
+    }
+  }
+  if constexpr (EPI == EPI_GELU) {
+    if (p.gelu_lp) {   // workgroup-uniform (kernel argument)
+      if (opt) {
+        if (edge) gemm_epilogue_impl<EPI, FM, FN, true, true, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+        else gemm_epilogue_impl<EPI, FM, FN, true, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      } else {
+        if (edge) gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+        else gemm_epilogue_impl<EPI, FM, FN, false, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      }
       return;
     }
   }

@@ -32,8 +32,9 @@ enum VjOpt {
   VJ_OPT_BIAS_FUSE,            // 1 (default, round 4): qkv / fc1 bias gradients from column partials written by the kernels that
                                // PRODUCE dY (attention backward, fc2-dgrad epilogue), one reduction launch per block;
                                // 0: stand-alone column-sum kernels re-reading dY
-  VJ_OPT_GELU_POLY,            // 1 (default, round 4): erf of the no-backward GELU epilogue by an odd minimax polynomial (no v_rcp /
-                               // v_exp); 0: Abramowitz-Stegun 7.1.26
+  VJ_OPT_GELU_POLY,            // 1 (default, round 4): the GELU epilogues take Phi(-|x|) as exp2 of a degree-6 polynomial in min(|x|, 5)
+                               // (6 FMAs + the one v_exp; no v_rcp, three multiplies fewer; closer to the correctly rounded bf16 erf-GELU
+                               // than 0:) Abramowitz-Stegun 7.1.26.  Results agree to one bf16 ulp on < 0.2 % of the inputs, not bitwise
   VJ_OPT_GEMM_SCHED,           // load / compute section pairs per K-tile of the persistent NT GEMM: 8 = four pairs of 16 MFMAs (round 3),
                                // 4 = two pairs of 32 MFMAs (round 4: half the section boundaries); bit-identical results
   VJ_OPT_ATTN_PSUM,            // 1 (default): the forward takes its soft-max row sums from the matrix pipe (head_dim 24: the V pad column of
