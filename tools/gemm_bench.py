@@ -30,22 +30,32 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cfgs", default="1.1,2.1,2.3", help="tile.pipeline pairs (see gemm.hip dispatch_gemm)")
     ap.add_argument("--no-wgrad", action="store_true", help="skip the split-K weight-gradient shapes")
+    ap.add_argument("--toggle", default=None, help="run-time option (vj_set_option name) measured at 0 and at 1 for every configuration")
+    ap.add_argument("--only", default=None, help="comma-separated substrings of the shape tags to run")
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     from jepa_amd.hip.lib import set_option
     # "4.0" = flags 0x100 (gemm4w.hip); "8.0" = automatic selection with the persistent 8-phase kernel (gemm8p.hip) enabled;
     # "8.4" = the same with option gemm_sched = 4 (two section pairs of 32 MFMAs per K-tile)
-    cfgs = [tuple(int(v) for v in c.split(".")) for c in args.cfgs.split(",")]
-    print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " + " ".join(f"t{c}p{q}(TF/s)" for c, q in cfgs))
-    for tag, M, N, K, epi in (STEP_SHAPES if args.no_wgrad else SHAPES):
+    cfgs = [tuple(int(v) for v in c.split(".")) + (None,) for c in args.cfgs.split(",")]
+    if args.toggle:
+        cfgs = [(c, q, t) for c, q, _ in cfgs for t in (0, 1)]
+    print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " +
+          " ".join(f"t{c}p{q}" + (f"{args.toggle}={t}" if t is not None else "") + "(TF/s)" for c, q, t in cfgs))
+    shapes = STEP_SHAPES if args.no_wgrad else SHAPES
+    if args.only:
+        shapes = [s for s in shapes if any(k.strip() in s[0] for k in args.only.split(","))]
+    for tag, M, N, K, epi in shapes:
         A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
         B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
         bias = torch.randn(N, device=dev, generator=g)
         aux = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16) if epi in (1, 2) else None
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
         res = []
-        for c, q in cfgs:
+        for c, q, tg in cfgs:
+            if tg is not None:
+                set_option(args.toggle, tg)
             flags = 0x100 if c == 4 else (0 if c == 8 else (c << 4) | (q << 6))
             set_option("gemm_persist", 1 if c == 8 else 0)
             set_option("gemm_sched", 4 if (c == 8 and q == 4) else 8)
