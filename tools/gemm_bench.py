@@ -64,7 +64,8 @@ def main():
                 if epi == 3:
                     ops.gemm_wgrad(A, B, out, flags=flags)
                 elif epi == 1:
-                    ops.gemm_nt(A, B, out=out, bias=bias, aux_out=aux, epilogue=1, flags=flags)
+                    # the target encoder runs no backward: its fc1 epilogue does not save gelu'
+                    ops.gemm_nt(A, B, out=out, bias=bias, aux_out=None if tag.startswith("tgt") else aux, epilogue=1, flags=flags)
                 elif epi == 2:
                     ops.gemm_nt(A, B, out=out, aux_in=aux, epilogue=2, flags=flags)
                 else:
