@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cfgs", default="1.1,2.1,2.3", help="tile.pipeline pairs (see gemm.hip dispatch_gemm)")
     ap.add_argument("--no-wgrad", action="store_true", help="skip the split-K weight-gradient shapes")
-    ap.add_argument("--toggle", default=None, help="run-time option (vj_set_option name) measured at 0 and at 1 for every configuration")
+    ap.add_argument("--toggle", default=None, help="run-time option (vj_set_option name[=v0,v1,...]) measured at each value (default 0 and 1) "
+                                                   "for every configuration")
     ap.add_argument("--only", default=None, help="comma-separated substrings of the shape tags to run")
     args = ap.parse_args()
     dev = "cuda"
@@ -39,8 +40,12 @@ def main():
     # "4.0" = flags 0x100 (gemm4w.hip); "8.0" = automatic selection with the persistent 8-phase kernel (gemm8p.hip) enabled;
     # "8.4" = the same with option gemm_sched = 4 (two section pairs of 32 MFMAs per K-tile)
     cfgs = [tuple(int(v) for v in c.split(".")) + (None,) for c in args.cfgs.split(",")]
+    tvals = (0, 1)
+    if args.toggle and "=" in args.toggle:
+        args.toggle, _, tv = args.toggle.partition("=")
+        tvals = tuple(int(v) for v in tv.split(","))
     if args.toggle:
-        cfgs = [(c, q, t) for c, q, _ in cfgs for t in (0, 1)]
+        cfgs = [(c, q, t) for c, q, _ in cfgs for t in tvals]
     print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>6s} epi " +
           " ".join(f"t{c}p{q}" + (f"{args.toggle}={t}" if t is not None else "") + "(TF/s)" for c, q, t in cfgs))
     shapes = STEP_SHAPES if args.no_wgrad else SHAPES
