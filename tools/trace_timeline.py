@@ -29,9 +29,17 @@ def main(path, n_steps=3):
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     ncol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     qcol = next((c for c in ("queue_id", "stream_id", "queue", "stream") if c in cols), None)
-    sel = f"select {ncol}, start, end" + (f", {qcol}" if qcol else "") + " from kernels order by start"
-    rows = [(short(r[0]), int(r[1]), int(r[2]), r[3] if qcol else 0) for r in cur.execute(sel)]
+    gcol = "grid_x" if "grid_x" in cols and "workgroup_x" in cols else None
+    sel = (f"select {ncol}, start, end" + (f", {qcol}" if qcol else ", 0") + (", grid_x, workgroup_x" if gcol else ", 0, 1") +
+           " from kernels order by start")
+    rows = []
+    for r in cur.execute(sel):
+        n = short(r[0])
+        if gcol and n.startswith(("gemm_", "attn_")):   # workgroup count tells the shapes of one kernel apart
+            n += f" [{int(r[4]) // max(1, int(r[5]))} wgs]"
+        rows.append((n, int(r[1]), int(r[2]), r[3]))
     marks = [i for i, r in enumerate(rows) if r[0].startswith("step_advance_kernel")]
+    dur = defaultdict(lambda: [0, 0.0])
     if len(marks) < 2:
         print(f"columns: {cols}\nonly {len(marks)} step_advance_kernel launches: need >= 2 steps")
         return
@@ -72,6 +80,8 @@ def main(path, n_steps=3):
     per_q = defaultdict(float)
     for n, s, e, q in win:
         per_q[q] += (min(e, t_hi) - max(s, t_lo))
+        dur[n][0] += 1
+        dur[n][1] += e - s
     print(f"# Kernel-timeline concurrency over the last {n_steps} steps of the trace ({span / n_steps:.2f} ms per step under the profiler)\n")
     print(f"columns of the kernels view: {', '.join(cols)}\n")
     print("| state | ms per step | share |")
@@ -97,10 +107,11 @@ def main(path, n_steps=3):
         after = g[3] if len(g) > 3 else "?"
         print(f"* {g[0] / 1e3:8.1f} us   `{g[2]}` -> `{after}`")
     print("\n## Time with exactly ONE kernel executing, by kernel (ms per step)\n")
-    print("| kernel | ms per step |")
-    print("|---|---|")
-    for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:16]:
-        print(f"| `{n}` | {v / 1e6 / n_steps:.2f} |")
+    print("| kernel [workgroups] | ms per step alone | launches per step | mean duration us | summed duration ms per step |")
+    print("|---|---|---|---|---|")
+    for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:28]:
+        c, d = dur[n]
+        print(f"| `{n}` | {v / 1e6 / n_steps:.2f} | {c / n_steps:.1f} | {d / c / 1e3:.1f} | {d / 1e6 / n_steps:.2f} |")
 
 
 if __name__ == "__main__":
