@@ -85,9 +85,8 @@ int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, const float
  *             the soft-max scale alpha = head_dim^-0.5 * log2(e) with ONE rounding; the attention entry points are then called with
  *             a NEGATIVE scale = "q is pre-scaled"; N % 12 == 0, no residual)
  * K % 32 == 0, N % 4 == 0, lda/ldb % 8 == 0.  flags bit0: register-staged operand path (A/B testing); bits 4-8: kernel selection
- * (0 = automatic); bit 9: the launch runs with no other kernel resident (the block chains' N = D dgrad GEMMs in the backward), so
- * the persistent kernel may use 192-row tiles where 256-row tiles leave CUs without a tile (option "gemm_bm192"; same bits out).
- * The GELU epilogues (1) evaluate Phi(-|x|) as exp2 of a degree-6 polynomial (option "gelu_poly", default; 0 = Abramowitz-Stegun). */
+ * (0 = automatic).  The GELU epilogues (1) evaluate Phi(-|x|) as exp2 of a degree-6 polynomial (option "gelu_poly", default;
+ * 0 = Abramowitz-Stegun 7.1.26): closer to the correctly rounded bf16 erf-GELU of nn.GELU() and one v_rcp + three multiplies cheaper. */
 int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                     int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
                     void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags,
@@ -348,7 +347,7 @@ int vj_comm_destroy(vj_comm_t comm);
  * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
  * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_tn",
  * "wgrad_group", "wgrad_slow_issue", "attn_dkdv_kt", "gemm_dbg", "attn_softmax", "bias_fuse", "gelu_poly", "gemm_sched", "attn_psum",
- * "attn_merge", "gemm_bm192" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * "attn_merge" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
  * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
 int vj_set_option(const char* name, int value);
 int vj_get_option(const char* name, int* value);

@@ -418,9 +418,6 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
   VJ_CHECK_ARG(heads > 0 && D % heads == 0, "vj_blocks_bwd: D=%ld not divisible by heads=%ld", (long)D, (long)heads);
   if (M == 0) return 0;
   const int g_dgrad_flags = vj_opt(VJ_OPT_GEMM_DGRAD_FLAGS);
-  // the three N = D dgrad GEMMs (fc1, proj, qkv) run with no other kernel resident for most of the backward (the weight-gradient stream is
-  // idle two thirds of it: profiles/r04_timeline_overlap.md): they may use 192-row tiles where 256-row tiles leave CUs without a tile
-  const int g_dgrad_bm = g_dgrad_flags | 0x200;
   const int64_t Dh = blocks[0].fc1.n_out, hd = D / heads;
   const float scale = (float)pow((double)hd, -0.5);   // head_dim ** -0.5 exactly as Attention.scale (modules.py:53) is computed on the host
   const FwdLayout F = fwd_layout(M, D, Dh, heads);
@@ -482,7 +479,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     }
     // fc1
     if (!grouped) CH(wgrad(sc, du, w + F.y2, b.fc1, fc1_fused != 0));
-    CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_bm));
+    CH(gemm(du, Dh, b.fc1.wT, b.fc1.ldwT, tmp + L.dy2, D, M, D, Dh, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     // dx1 is the dY of proj: its bias gradient = column sums of dx1, produced by this pass
     if (bfuse) {
       int64_t nb2 = 0;
@@ -501,7 +498,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     }
     // proj
     if (!grouped) CH(wgrad(sc, dx1, w + F.o, b.proj, fuse_cs));
-    CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_bm));
+    CH(gemm(dx1, D, b.proj.wT, b.proj.ldwT, tmp + L.dob, D, M, D, D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, stream, g_dgrad_flags));
     // qkv bias: column partials from the attention backward kernels, when every segment's partial rows fit the workspace
     int64_t rows_q = 0, rows_kv = 0;
     bool qkv_fused = bfuse && b.qkv.gb != nullptr;
@@ -563,7 +560,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
       CH(wgrad(sc, dqkv, w + F.y1, b.qkv, qkv_fused));
     }
     CH(gemm(dqkv, 3 * D, b.qkv.wT, b.qkv.ldwT, tmp + L.dy1, D, M, D, 3 * D, nullptr, nullptr, 0, nullptr, nullptr, 0, 0,
-            stream, g_dgrad_bm));
+            stream, g_dgrad_flags));
     // dx is the dY of the previous block's fc2 (its dx2): that bias gradient comes out of this pass
     if (bfuse) {
       int64_t nb1 = 0;

@@ -258,8 +258,7 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
   return 0;
 }
 
-// flags: bit0 = register-staged operands (A/B testing); bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256); bit 9 = the launch
-//        may use 192-row tiles where the persistent kernel's rule finds them faster (gemm8p.hip pick_bm192; results bit-identical);
+// flags: bit0 = register-staged operands (A/B testing); bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256);
 //        bits 6-7 = pipeline (0 auto, 1 = BK64 double buffer, 2 = BK32 4-stage ring with counted vmcnt,
 //                   3 = 256x256 staggered 8-phase schedule, gemm8.hip)
 int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);  // gemm8.hip
@@ -355,7 +354,6 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.zero_row = nullptr;
   a.colpart = nullptr;
   a.gelu_lp = vj_opt(VJ_OPT_GELU_POLY);
-  a.bm192 = (flags & 0x200) ? 1 : 0;   // flags bit 9: this launch may use 192-row tiles (persistent kernel, option gemm_bm192)
   a.qscale = qscale;
   a.qcols = qscale != 0.f ? N / 3 : 0;
   switch (epilogue) {
@@ -406,7 +404,6 @@ extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const vo
     a.qcols = 0;
     a.colpart = colpart;
     a.gelu_lp = 0;
-    a.bm192 = 0;
     const int rc = vj_gemm_launch_8phase_persist(a, EPI_DGELU, stream);
     if (rc != -100) {
       *fused = (rc == 0);

@@ -31,16 +31,6 @@
 //   TAIL1    K-tile nk-1: phases 0..3 issue the next tile's B0(0) | B1(0) | A1(0) + B0(1) | A0(1) + B1(1); the two extra
 //            parts go to slots of THIS K-tile whose fragments were read two sections earlier (WAR rule of the template)
 //   epilogue bias loads + vmcnt(0) (every DMA issued so far has landed for this wave), convert, stage, store
-// Tile height FI (template): 4 = 256 rows (wave tile 128 x 64), 3 = 192 rows (wave tile 96 x 64, three 16-row MFMA blocks per
-// accumulator quadrant instead of four).  The 192-row tile exists for the context encoder's N = 1024 dgrad GEMMs (M ~ 10^4):
-// 42 x 4 = 168 tiles of 256 rows leave a third of the 256 CUs without a tile, 55 x 4 = 220 tiles of 192 rows run in one round of
-// ~0.8 tile times.  Nothing else changes: the A parts keep their 128-row LDS image (rows 48..63 of each 64-row half re-read row 47
-// and are never touched by a fragment read), so the part stream, the ring and the counted vmcnt are identical; every output element
-// is accumulated in the same K order by the same MFMA -> still bit-identical.  Round 3 built this for every launch of those shapes and
-// lost 0.9 % of step time (profiles/r03_gemm_bm192.md: in the FORWARD the other stream was using the 'idle' CUs); the kernel timeline
-// of round 4 (profiles/r04_timeline_overlap.md) shows that the BACKWARD runs these GEMMs with no other kernel resident for 5.4 ms per
-// step, so the tile height is now a per-launch permission (GemmArgs::bm192, flags bit 9 of vj_gemm_bf16_nt) that only the block chains'
-// dgrad GEMMs give (option gemm_bm192).
 // Requirements (checked by the launcher, otherwise the one-tile kernel runs): bf16 output epilogues, M, N >= 256,
 // K % 64 == 0, K >= 256, more tiles than CUs, 16-byte-aligned rows of C (and aux), C not aliasing the residual.
 #include <type_traits>
@@ -72,31 +62,28 @@ __device__ __forceinline__ void pp_dma(const char* sbase, unsigned voff, unsigne
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
-// the 8 wave-uniform row-group bases of one tile: A rows m0 + j*(32 FI) + mq*(16 FI), B rows n0 + j*128 + nq*32 (byte pointers at k = 0)
+// the 8 wave-uniform row-group bases of one tile: A rows m0 + j*128 + mq*64, B rows n0 + j*128 + nq*32 (byte pointers at k = 0)
 struct PpBases {
   const char* a[2][2];   // [mq][j]
   const char* b[2][2];   // [nq][j]
 };
-template <int FI>
 __device__ __forceinline__ void pp_make_bases(PpBases& pb, const char* a0, const char* b0, int64_t lda2, int64_t ldb2) {
 #pragma unroll
   for (int sub = 0; sub < 2; sub++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      pb.a[sub][j] = a0 + (int64_t)(j * (FI * 32) + sub * (FI * 16)) * lda2;
+      pb.a[sub][j] = a0 + (int64_t)(j * 128 + sub * 64) * lda2;
       pb.b[sub][j] = b0 + (int64_t)(j * 128 + sub * 32) * ldb2;
     }
 }
 
-// logical tile index -> shifted tile origin (always a full (64 FI) x 256 tile inside the matrix)
-template <int FI>
+// logical tile index -> shifted tile origin (always a full 256 x 256 tile inside the matrix)
 __device__ __forceinline__ void pp_tile_origin(const GemmArgs& p, int logical, int64_t& m0, int64_t& n0, int& tm) {
-  constexpr int BM = FI * 64;
   int tn;
   tile_of(logical, p.tiles_m, p.tiles_n, tm, tn);
-  m0 = (int64_t)tm * BM;
+  m0 = (int64_t)tm * 256;
   n0 = (int64_t)tn * 256;
-  m0 = m0 + BM <= p.M ? m0 : p.M - BM;
+  m0 = m0 + 256 <= p.M ? m0 : p.M - 256;
   n0 = n0 + 256 <= p.N ? n0 : p.N - 256;
 }
 
@@ -104,9 +91,8 @@ enum { PP_STEADY = 0, PP_HEAD0, PP_HEAD1, PP_TAIL0, PP_TAIL1 };
 
 // SCHED = 8: the round-3 schedule (four {load, compute} pairs per K-tile, 16 MFMAs per compute section);
 // SCHED = 4 (round 4): TWO pairs per K-tile, 32 MFMAs per compute section -- see k_tile4 below.
-template <int EPI, int SCHED, int FI = 4>
+template <int EPI, int SCHED>
 __device__ __forceinline__ void pp_body(const GemmArgs& p) {
-  static_assert(FI == 4 || (FI == 3 && EPI == EPI_BF16 && SCHED == 4), "192-row tiles: bf16 epilogue, 4-section schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,8 +121,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     const int r0 = tid >> 3, cpos = tid & 7;
     const int c = cpos ^ (r0 & 7);
     const int rb = (r0 >> 5) * 64 + (r0 & 31);        // B parts interleave the four wave columns' 32-row halves
-    const int ra = r0 < FI * 16 ? r0 : FI * 16 - 1;   // 192-row tiles: LDS rows 48..63 of a half re-read row 47 (never read back)
-    voff_a = (unsigned)((ra * p.lda + c * 8) * 2);
+    voff_a = (unsigned)((r0 * p.lda + c * 8) * 2);
     voff_b = (unsigned)((rb * p.ldb + c * 8) * 2);
   }
   const unsigned ring = pp_lds(smem);
@@ -167,8 +152,8 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
       pp_dma(b0n + (int64_t)(128 + KIND * 32) * ldb2, voff_b + koff, slot + 512 * 16);
     } else {
       constexpr int MQ = KIND == 2 ? 1 : 0;
-      pp_dma(a0n + (int64_t)(MQ * (FI * 16)) * lda2, voff_a + koff, slot);
-      pp_dma(a0n + (int64_t)(FI * 32 + MQ * (FI * 16)) * lda2, voff_a + koff, slot + 512 * 16);
+      pp_dma(a0n + (int64_t)(MQ * 64) * lda2, voff_a + koff, slot);
+      pp_dma(a0n + (int64_t)(128 + MQ * 64) * lda2, voff_a + koff, slot + 512 * 16);
     }
   };
   using K_B0 = std::integral_constant<int, 0>;
@@ -177,12 +162,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   using K_A0 = std::integral_constant<int, 3>;
 
   // per-lane fragment byte offsets inside a part (rows are 128 B, chunks XOR-swizzled by row & 7)
-  int a_off[FI][2], b_off[2][2];
+  int a_off[4][2], b_off[2][2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
     const int c = ks * 4 + fg;
 #pragma unroll
-    for (int i = 0; i < FI; i++) {
+    for (int i = 0; i < 4; i++) {
       const int pr = wm * 64 + i * 16 + frow;
       a_off[i][ks] = pr * 128 + ((c ^ (pr & 7)) * 16);
     }
@@ -193,12 +178,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     }
   }
 
-  f32x4_t acc[2 * FI][4];
-  bf16x8_t ra0[FI][2], ra1[FI][2], rb0[2][2], rb1[2][2];  // [fragment][k-step]
+  f32x4_t acc[8][4];
+  bf16x8_t ra0[4][2], ra1[4][2], rb0[2][2], rb1[2][2];  // [fragment][k-step]
 
-  auto read_a = [&](bf16x8_t (&ra)[FI][2], const char* slot) __attribute__((always_inline)) {
+  auto read_a = [&](bf16x8_t (&ra)[4][2], const char* slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < FI; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) ra[i][ks] = *(const bf16x8_t*)(slot + a_off[i][ks]);
   };
@@ -208,17 +193,17 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) rb[j][ks] = *(const bf16x8_t*)(slot + b_off[j][ks]);
   };
-  auto mma = [&](auto quad_tag, const bf16x8_t (&rb)[2][2], const bf16x8_t (&ra)[FI][2]) __attribute__((always_inline)) {
+  auto mma = [&](auto quad_tag, const bf16x8_t (&rb)[2][2], const bf16x8_t (&ra)[4][2]) __attribute__((always_inline)) {
     constexpr int QI = decltype(quad_tag)::value >> 1, QJ = decltype(quad_tag)::value & 1;   // accumulator quadrant
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-      for (int i = 0; i < FI; i++)
+      for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
-          acc[FI * QI + i][2 * QJ + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[j][ks], ra[i][ks], acc[FI * QI + i][2 * QJ + j], 0, 0, 0);
+          acc[4 * QI + i][2 * QJ + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[j][ks], ra[i][ks], acc[4 * QI + i][2 * QJ + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
   using Q00 = std::integral_constant<int, 0>;
@@ -362,8 +347,8 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   // ---- first tile: parts -1 .. 5 in flight, all landed before anybody reads
   int64_t m0, n0;
   int tm_cur;                                  // un-shifted row-tile index of the current tile (column-sum slot / row ownership)
-  pp_tile_origin<FI>(p, band0 + pos, m0, n0, tm_cur);
-  pp_make_bases<FI>(cur, (const char*)(p.A + m0 * p.lda), (const char*)(p.B + n0 * p.ldb), lda2, ldb2);
+  pp_tile_origin(p, band0 + pos, m0, n0, tm_cur);
+  pp_make_bases(cur, (const char*)(p.A + m0 * p.lda), (const char*)(p.B + n0 * p.ldb), lda2, ldb2);
   int h = 0;                                   // ring half of the current tile's K-tile 0 (toggles every K-tile, across tiles)
   issue(K_A0{}, cur, 0, 1);                    // part -1: A0(0) -> half h^1, slot 3
   issue(K_B0{}, cur, 0, 0);
@@ -378,11 +363,11 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     const bool has_next = ti + 1 < my_tiles;   // workgroup-uniform
     int64_t m0n, n0n;
     int tm_next;
-    pp_tile_origin<FI>(p, band0 + pos + (has_next ? ti + 1 : ti) * wgs_x, m0n, n0n, tm_next);
+    pp_tile_origin(p, band0 + pos + (has_next ? ti + 1 : ti) * wgs_x, m0n, n0n, tm_next);
     a0n = (const char*)(p.A + m0n * p.lda);
     b0n = (const char*)(p.B + n0n * p.ldb);
 #pragma unroll
-    for (int i = 0; i < 2 * FI; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     // ---- tile start: part 6 = A1(1) -> half h^1 slot 2 (its previous content, A1 of the previous tile's last K-tile, was
@@ -416,7 +401,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     //      (bias loads + s_waitcnt vmcnt(0)) also retires every LDS-DMA this wave has issued.
     if (p.dbg & 1) {   // diagnostics: no output traffic (keeps the accumulators alive through one predicated store)
       pp_wait<0>();
-      if (acc[0][0][0] == 12345.678f && acc[2 * FI - 1][3][3] == 0.5f) *(float*)p.C = acc[3][2][1];
+      if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 0.5f) *(float*)p.C = acc[3][2][1];
     } else {
       // lane id re-derived through a VOLATILE asm: everything the epilogue computes from it (LDS staging offsets, row /
       // column addresses) is then re-computed per tile instead of being hoisted out of the tile loop, where it would
@@ -426,14 +411,14 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
       const int efrow = elane & 15, efg = elane >> 4;
       pp_wait<0>();
       // (column sums, EPI_DGELU with p.colpart: a shifted edge tile owns only its rows >= tm * 256; slot = 2 tm + wave row)
-      (void)gemm_epilogue_try_staged<EPI, 2, 2 * FI>(p, acc, m0 + wm * (FI * 32), n0 + wn * 64, efrow, efg, elane,
-                                                     smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * (FI * 64),
-                                                     tm_cur * 2 + wm);
+      (void)gemm_epilogue_try_staged<EPI, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+                                             smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
+                                             tm_cur * 2 + wm);
     }
     m0 = m0n;
     n0 = n0n;
     tm_cur = tm_next;
-    pp_make_bases<FI>(cur, a0n, b0n, lda2, ldb2);
+    pp_make_bases(cur, a0n, b0n, lda2, ldb2);
   }
 }
 
@@ -444,10 +429,6 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_kernel(GemmArgs p) {
   pp_body<EPI, 4>(p);
-}
-// 192-row tiles (bf16 epilogue only: the context encoder's N = 1024 dgrad GEMMs)
-__global__ __launch_bounds__(512) void gemm_nt_4phase_persist_bm192_kernel(GemmArgs p) {
-  pp_body<EPI_BF16, 4, 3>(p);
 }
 
 int g_num_cus = 0;   // CU count of the (homogeneous) GPUs of this node, read once
@@ -478,30 +459,15 @@ static bool persist_ok(const GemmArgs& a, int ncu) {
   return true;
 }
 
-// Tile height of a launch that may use 192-row tiles (GemmArgs::bm192): 192 only where the 256-row grid is ONE under-filled round and
-// the 192-row grid is still one round and at least a fifth larger (ViT-L context encoder, N = 1024: 168 -> 220 tiles).  A 192-row
-// K-tile takes ~0.81 of a 256-row one (24 instead of 32 MFMAs per section over the same barriers, LDS-DMA and B fragment reads), so a
-// second round would lose.  Option gemm_bm192: 0 never, 1 (default) launches that carry the permission, 2 every launch (A/B).
-template <int EPI>
-static bool pick_bm192(const GemmArgs& a, int ncu) {
-  if (EPI != EPI_BF16 || a.M < 192 || vj_opt(VJ_OPT_GEMM_SCHED) != 4) return false;
-  const int opt = vj_opt(VJ_OPT_GEMM_BM192);
-  if (opt == 0 || (opt == 1 && !a.bm192)) return false;
-  const int64_t tn = cdiv64(a.N, 256);
-  const int64_t t256 = cdiv64(a.M, 256) * tn, t192 = cdiv64(a.M, 192) * tn;
-  return t256 <= ncu && t192 <= ncu && t192 * 5 >= t256 * 6;
-}
-
 template <int EPI>
 static int launch8p(const GemmArgs& a, hipStream_t stream) {
   constexpr int smem = PP_RING + 8 * PP_STAGE_PER_WAVE;   // 160 KB: the whole LDS of a CU
-  const bool bm192 = pick_bm192<EPI>(a, g_num_cus);
   static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
   attr_once([] {
     (void)hipFuncSetAttribute((const void*)gemm_nt_8phase_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   });
   GemmArgs b = a;
-  b.tiles_m = (int)cdiv64(a.M, bm192 ? 192 : 256);
+  b.tiles_m = (int)cdiv64(a.M, 256);
   b.tiles_n = (int)cdiv64(a.N, 256);
   b.splitk = 1;
   b.ws = nullptr;
@@ -520,13 +486,7 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
     if (per_xcd * 8 > g_num_cus) per_xcd = g_num_cus / 8;
     grid = (int)(per_xcd * 8);
   }
-  if (bm192) {
-    static VjPerDeviceOnce attr192_once;
-    attr192_once([] {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_bm192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    });
-    hipLaunchKernelGGL(gemm_nt_4phase_persist_bm192_kernel, dim3(grid), dim3(512), smem, stream, b);
-  } else if (vj_opt(VJ_OPT_GEMM_SCHED) == 4) {
+  if (vj_opt(VJ_OPT_GEMM_SCHED) == 4) {
     static VjPerDeviceOnce attr4_once;
     attr4_once([] {
       (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

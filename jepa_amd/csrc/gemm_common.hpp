@@ -25,7 +25,6 @@ struct GemmArgs {
   int64_t qcols;       //   of a qkv projection carries the soft-max scale scale*log2(e): ONE rounding of c*q, attention.hip); qcols % 4 == 0
   float* colpart;      // EPI_DGELU on the persistent kernel, nullable: fp32 column-sum partials of the OUTPUT, [2 * tiles_m][N]
                        // (row slot = 2 * row tile + wave row): the bias gradient of the Linear whose dY this GEMM produces
-  int bm192;           // persistent kernel, EPI_BF16: != 0 -> 192-row tiles are allowed for this launch (gemm8p.hip pick_fi)
   int gelu_lp;         // EPI_GELU: != 0 -> Phi(-|x|) = exp2(degree-6 polynomial) (common.hpp, option gelu_poly); 0 -> A-S 7.1.26
 };
 
@@ -188,17 +187,16 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 // rows below `row_lo` -- the part of a SHIFTED edge tile that belongs to its neighbour -- are left out) and writes the 64
 // column sums to p.colpart[slot][n_base ..]: du = dY of fc1 is produced here, so fc1's bias gradient costs 64 packed FMAs + 64
 // DPP adds per wave tile instead of a second pass over du (colsum_bf16_kernel: 84 MB per ViT-L context block).
-template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false, int FM = 8>
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[FM][4], int64_t m_base,
+template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage,
                                                      int64_t row_lo = 0, int slot = 0) {
   // IPP = 16-row blocks per pass: 8 -> the whole wave tile in one 16 KB pass (stage = 16 KB per wave, the dead operand
   // ring of the one-tile-per-workgroup kernel); 2 -> four 4 KB passes (persistent kernel: the ring already holds the
   // next tile's first parts, the staging area is a separate 32 KB).
   static_assert(EPI != EPI_F32, "fp32 outputs are stored directly");
-  // FM = 16-row blocks of the wave tile: 8 (128 rows) or, for the 192-row tiles of the persistent kernel, 6
-  static_assert((IPP == 8 || IPP == 2) && FM % IPP == 0, "passes of 128 or 32 rows");
-  constexpr int FN = 4;
+  static_assert(IPP == 8 || IPP == 2, "passes of 128 or 32 rows");
+  constexpr int FM = 8, FN = 4;
   const int64_t ncol0 = n_base + fg * 4;
   int64_t ncl[FN];
 #pragma unroll
@@ -363,8 +361,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
 
 // staged variant selector for the 8-phase kernel (wave tile 128 x 64); falls back to the direct form when the 16-byte
 // row-major stores cannot be used (N, ldc or the base pointers not 8-element aligned) and for fp32 outputs
-template <int EPI, int IPP = 8, int FM = 8>
-__device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[FM][4], int64_t m_base,
+template <int EPI, int IPP = 8>
+__device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                          int64_t n_base, int frow, int fg, int lane, char* stage,
                                                          int64_t row_lo = 0, int slot = 0) {
   if constexpr (EPI == EPI_F32) {
@@ -377,38 +375,38 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     if constexpr (EPI == EPI_GELU) opt = p.aux_out != nullptr;
     else if constexpr (EPI == EPI_BF16) opt = p.res != nullptr;
     else opt = true;
-    const bool edge = __builtin_amdgcn_readfirstlane((m_base + FM * 16 > p.M) || (n_base + 64 > p.N));
+    const bool edge = __builtin_amdgcn_readfirstlane((m_base + 128 > p.M) || (n_base + 64 > p.N));
     if constexpr (EPI == EPI_DGELU && IPP == 2) {   // persistent kernel (every tile interior): optional fused column sums
       if (p.colpart != nullptr && !edge) {
-        gemm_epilogue_staged<EPI, true, false, IPP, true, false, false, FM>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot);
+        gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot);
         return true;
       }
     }
     if constexpr (EPI == EPI_BF16) {
       if (p.qscale != 0.f && n_base < p.qcols) {   // wave tiles that hold q columns only (the launcher guarantees: no residual)
-        if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true, false, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
-        else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        else gemm_epilogue_staged<EPI, false, false, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
         return true;
       }
     }
     if constexpr (EPI == EPI_GELU) {
       if (p.gelu_lp) {   // workgroup-uniform (kernel argument)
         if (opt) {
-          if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, true, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
-          else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
         } else {
-          if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
-          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
         }
         return true;
       }
     }
     if (opt) {
-      if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, false, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
-      else gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      else gemm_epilogue_staged<EPI, true, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
     } else if constexpr (EPI != EPI_DGELU) {
-      if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
-      else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, FM>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      if (edge) gemm_epilogue_staged<EPI, false, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      else gemm_epilogue_staged<EPI, false, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
     }
     return true;
   }

@@ -41,9 +41,6 @@ enum VjOpt {
                                // the P.V MFMA; other head sizes: an all-ones operand, two extra MFMAs per key tile); 0: vector adds
   VJ_OPT_ATTN_MERGE,           // 1 (default): the chains launch attention ONCE per block for all segments (masks) of the batch
                                // (vj_attn_fwd_segs / vj_attn_bwd_segs); 0: one launch (pair) per segment.  Bit-identical results
-  VJ_OPT_GEMM_BM192,           // 192-row tiles in the persistent NT GEMM for under-filled single-round launches (gemm8p.hip pick_bm192; bit-identical):
-                               // 0 never; 1 (default) only launches that carry the permission (flags bit 9 of vj_gemm_bf16_nt: the block chains'
-                               // N = D dgrad GEMMs, which run in the backward with no other kernel resident); 2 every launch the rule accepts
   VJ_OPT_COUNT
 };
 

@@ -537,60 +537,3 @@ def test_gelu_poly_epilogue(ops, M):
     d = dg[0].cpu().double()
     assert float((d - xg.grad).abs().max()) < 5e-3        # half a bf16 ulp at 1.13 (4e-3) + the q error
     assert rel_l2(d, xg.grad) < 3e-3
-
-
-# ------------------------------------------------------------------------------------------ 192-row tiles of the persistent GEMM
-@pytest.mark.parametrize("M,N,K,qkv", [
-    (10560, 1024, 1024, False),   # the step's context-encoder dproj: 168 tiles of 256 rows -> 220 of 192
-    (10176, 1024, 4096, False),   # ... dfc1 (64 K-tiles)
-    (9074, 1024, 320, False),     # M not a multiple of 192 (shifted last row tile), ODD K-tile count
-    (3000, 768, 256, False),      # the minimum K, three column tiles
-    (2000, 1536, 512, True),      # epilogue 4: q columns scaled before the rounding, on 96 x 64 wave tiles
-])
-def test_persistent_gemm_192_row_tiles_are_bit_identical(ops, M, N, K, qkv):
-    """Option gemm_bm192 = 2 (every launch the rule accepts; 1 = only launches flagged by the block chains' dgrad GEMMs): the
-    192-row tile variant of gemm8p.hip (wave tile 96 x 64) must give the bits of the 256-row kernel -- same K order per output,
-    same epilogue arithmetic -- with bias, residual and the q-column scale.  Three operand draws per case."""
-    for seed in range(3):
-        g = torch.Generator(device=DEV).manual_seed(500 + seed)
-        A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
-        W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
-        bias = torch.randn(N, device=DEV, generator=g)
-        res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
-        variants = [dict(bias=bias), dict(bias=None), dict(bias=bias, residual=res)]
-        if qkv:
-            variants = [dict(bias=bias, epilogue=ops.EPI_QKV, alpha=0.125 * LOG2E)]
-        for kw in variants:
-            outs = []
-            for opt in (0, 2):
-                with _opt("gemm_bm192", opt):
-                    out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
-                    ops.gemm_nt(A, W, out=out, **kw)
-                    torch.cuda.synchronize()
-                    outs.append(out)
-            assert not torch.isnan(outs[1].float()).any(), (seed, sorted(kw), "unwritten output")
-            assert torch.equal(outs[0], outs[1]), (seed, sorted(kw), int((outs[0] != outs[1]).sum()))
-        ref = A.float() @ W.float().t() + bias
-        got = ops.gemm_nt(A, W, bias=bias)
-        assert rel_l2(got, ref) < 4e-3
-
-
-@pytest.mark.timeout(600)
-def test_step_with_192_row_dgrad_tiles_is_bit_identical_vitl_b24():
-    """The C block chain flags its N = D dgrad GEMMs (fc1, proj, qkv) for 192-row tiles (option gemm_bm192 = 1, default): at the
-    benched configuration (ViT-L/16, B = 24: context rows ~ 10^4, the shape the rule accepts) the same step with the option off,
-    on, and forced on every launch (2: the forward's proj / fc2 GEMMs as well) gives identical loss and gradient arena."""
-    from tests.step_util import VITL, VITL_MASKS
-    from oracle import vjepa_oracle as O
-    tr, _, _, _, _ = build_trainer(VITL, 2)
-    gens = O.make_mask_gens(VITL_MASKS, VITL["crop"], VITL["frames"], VITL["patch"], VITL["tubelet"])
-    clips, me, mp = draw_batch(gens, 24, VITL, 1234, 4321)
-    cd, med, mpd = to_dev(clips, me, mp)
-    res = []
-    for opt in (0, 1, 2):
-        with _opt("gemm_bm192", opt):
-            o = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
-            res.append((o.loss, tr.arena.G.clone()))
-    assert bool(torch.isfinite(res[0][1]).all())
-    for opt in (1, 2):
-        assert res[opt][0] == res[0][0] and torch.equal(res[opt][1], res[0][1]), opt
