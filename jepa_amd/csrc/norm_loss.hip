@@ -7,6 +7,7 @@
 //   loss_fn: mean(|z-h|^p)/p averaged over masks         app/vjepa/train.py:440-446
 //   reg_fn : sqrt(var_tokens(z)+1e-4)                    app/vjepa/train.py:448-449,458
 #include "common.hpp"
+#include "options.hpp"
 
 int vj_reduce_partials_multi(const float* part, float* const* outs, int nseg, int64_t P, int64_t D, float alpha, float beta,
                              hipStream_t stream);   // rows.hip
@@ -133,7 +134,7 @@ extern "C" int vj_layernorm_fwd(const void* x_bf16, const float* gamma, const fl
 // separate read of dY each (the transpose-free weight-gradient route has no transpose pass to fold them into).
 // ---------------------------------------------------------------------------------------------
 #define LN_BWD_MAX_BLOCKS 1024
-template <int NCH, bool CS>
+template <int NCH, bool CS, bool PF = true>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in,
@@ -158,24 +159,64 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   const int64_t rows_per = cdiv64(rows, gridDim.x);
   const int64_t rbeg = (int64_t)blockIdx.x * rows_per;
   const int64_t rend = (rbeg + rows_per < rows) ? rbeg + rows_per : rows;
+  // Software prefetch, one row ahead (round 4): a wave used to load x | dy of its row, wait, reduce, THEN load the residual gradient, and
+  // read the row's mean / rstd with a dependent scalar-sized load at the top of every iteration -- three exposed memory latencies per
+  // row with ~10 waves per CU on the context-encoder launches (660 workgroups): 3.2 TB/s.  Now the raw 16-byte chunks of x, dy, dres
+  // and the two statistics of row r + 4 are requested before row r is computed.  Same arithmetic in the same order: bit-identical.
+  u32x4_t nx[NCH], nd[NCH], nr[NCH];
+  float nmean = 0.f, nrstd = 0.f;
+  auto request = [&](int64_t r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+        nx[i] = *(const u32x4_t*)(x + r * D + c);
+        nd[i] = *(const u32x4_t*)(dy + r * D + c);
+        if (dres) nr[i] = *(const u32x4_t*)(dres + r * D + c);
+      }
+    }
+    nmean = mean_in[r];
+    nrstd = rstd_in[r];
+  };
+  auto unpack8 = [](const u32x4_t& w, float* v) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      v[2 * i] = bf_lo(w[i]);
+      v[2 * i + 1] = bf_hi(w[i]);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NCH; i++) nx[i] = nd[i] = nr[i] = (u32x4_t){0u, 0u, 0u, 0u};
+  if (PF && rbeg + wv < rend) request(rbeg + wv);
   for (int64_t r = rbeg + wv; r < rend; r += 4) {
-    const float mean = mean_in[r], rstd = rstd_in[r];
-    float xh[NCH][8], g[NCH][8];
+    if constexpr (!PF) request(r);   // option ln_bwd_prefetch = 0 (A/B): the row is requested when it is needed
+    u32x4_t cx[NCH], cd[NCH], cr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      cx[i] = nx[i];
+      cd[i] = nd[i];
+      cr[i] = nr[i];
+    }
+    const float mean = nmean, rstd = nrstd;
+    if (PF && r + 4 < rend) request(r + 4);
+    // (the second pass recomputes xhat and g from the raw chunks -- the same operations on the same operands, hence the same bits --
+    //  instead of keeping 16 floats per chunk alive across the two wave reductions: with the prefetch buffers that keeps the
+    //  D = 1024 variant at three waves per SIMD, i.e. its 660 workgroups resident in one round)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
       const int c = lane * 8 + i * 512;
       if (c < D) {
         float xv[8], dv[8];
-        load8(x + r * D + c, xv);
-        load8(dy + r * D + c, dv);
+        unpack8(cx[i], xv);
+        unpack8(cd[i], dv);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          xh[i][j] = (xv[j] - mean) * rstd;
-          g[i][j] = dv[j] * gam[i][j];
-          s1 += g[i][j];
-          s2 += g[i][j] * xh[i][j];
-          ag[i][j] += dv[j] * xh[i][j];
+          const float xh = __fmul_rn(__fsub_rn(xv[j], mean), rstd);   // (rounded products: never contracted into the FMAs below,
+          const float g = __fmul_rn(dv[j], gam[i][j]);                //  so both passes see the same xhat and g)
+          s1 += g;
+          s2 += g * xh;
+          ag[i][j] += dv[j] * xh;
           ab[i][j] += dv[j];
         }
       }
@@ -185,15 +226,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     for (int i = 0; i < NCH; i++) {
       const int c = lane * 8 + i * 512;
       if (c < D) {
-        float o[8];
+        float o[8], xv[8], dv[8];
+        unpack8(cx[i], xv);
+        unpack8(cd[i], dv);
         if (dres) {
-          load8(dres + r * D + c, o);
+          unpack8(cr[i], o);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; j++) o[j] = 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] += rstd * (g[i][j] - c1 - xh[i][j] * c2);
+        for (int j = 0; j < 8; j++) {
+          const float xh = __fmul_rn(__fsub_rn(xv[j], mean), rstd);   // (rounded products: never contracted into the FMAs below,
+          const float g = __fmul_rn(dv[j], gam[i][j]);                //  so both passes see the same xhat and g)
+          o[j] += rstd * (g - c1 - xh * c2);
+        }
         if constexpr (CS) {
 #pragma unroll
           for (int j = 0; j < 8; j++) as[i][j] += o[j];
@@ -241,10 +288,16 @@ int vj_layernorm_bwd_partials(const void* dy_bf16, const void* x_bf16, const flo
   int64_t nb = cdiv64(rows, 16);  // >= 16 rows per workgroup so the column partials amortise
   if (nb > LN_BWD_MAX_BLOCKS) nb = LN_BWD_MAX_BLOCKS;
   if (nb < 1) nb = 1;
-#define VJ_LNB(NCHV, CSV)                                                                                               \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<NCHV, CSV>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16, \
-                     (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws,    \
+  const bool pf = vj_opt(VJ_OPT_LN_BWD_PREFETCH) != 0;
+#define VJ_LNB1(NCHV, CSV, PFV)                                                                                               \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NCHV, CSV, PFV>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16, \
+                     (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws,         \
                      rows, (int)D)
+#define VJ_LNB(NCHV, CSV)           \
+  do {                              \
+    if (pf) VJ_LNB1(NCHV, CSV, true); \
+    else VJ_LNB1(NCHV, CSV, false);   \
+  } while (0)
   if (cs) {
     if (D <= 512) VJ_LNB(1, true);
     else if (D <= 1024) VJ_LNB(2, true);
@@ -257,6 +310,7 @@ int vj_layernorm_bwd_partials(const void* dy_bf16, const void* x_bf16, const flo
     else VJ_LNB(4, false);
   }
 #undef VJ_LNB
+#undef VJ_LNB1
   VJ_LAUNCH_CHECK("vj_layernorm_bwd");
   *nb_out = nb;
   return 0;
