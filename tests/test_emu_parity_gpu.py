@@ -78,15 +78,94 @@ def test_micro_step_vs_bf16_emulating_oracle():
         eh, ez, ep = rel_l2(h[i].cpu(), oe["h"][i]), rel_l2(zenc[i].float().cpu(), oe["z_enc"][i]), rel_l2(zpred[i].float().cpu(), oe["z"][i])
         print(f"[micro] mask {i}: h {eh:.2e} (fp32 oracle {rel_l2(h[i].cpu(), o32['h'][i]):.2e}), z_enc {ez:.2e} "
               f"({rel_l2(zenc[i].float().cpu(), o32['z_enc'][i]):.2e}), z {ep:.2e} ({rel_l2(zpred[i].float().cpu(), o32['z'][i]):.2e})")
-        assert eh < 4e-3 and ez < 4e-3 and ep < 4e-3, (i, eh, ez, ep)
+        assert eh < 1e-3 and ez < 1e-3 and ep < 2e-3, (i, eh, ez, ep)          # measured 2.1e-4 / 1.6e-4 / 7.3e-4; fp32 oracle: 5e-3
     out = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
-    _compare(tr, oe, ge, o32, g32, out, "micro", dict(loss=2e-4, grad=2e-2))
+    _compare(tr, oe, ge, o32, g32, out, "micro", dict(loss=2e-5, grad=1.5e-2))   # measured 3.1e-6 / 6.9e-3; fp32 oracle: 2.2e-5 / 2.6e-2
+
+
+def _build_shallow(c, seed):
+    """Encoder / predictor of arbitrary small dimensions through the reference-named module classes (as build_micro_modules)."""
+    from functools import partial
+    import torch.nn as nn
+    from jepa_amd.src.models.predictor import VisionTransformerPredictor
+    from jepa_amd.src.models.utils.multimask import MultiMaskWrapper, PredictorMultiMaskWrapper
+    from jepa_amd.src.models.vision_transformer import VisionTransformer
+    torch.manual_seed(seed)
+    enc = VisionTransformer(img_size=c["crop"], patch_size=c["patch"], num_frames=c["frames"], tubelet_size=c["tubelet"],
+                            embed_dim=c["embed_dim"], depth=c["depth"], num_heads=c["heads"], mlp_ratio=4, qkv_bias=True,
+                            norm_layer=partial(nn.LayerNorm, eps=1e-6), uniform_power=True)
+    pred = VisionTransformerPredictor(img_size=c["crop"], patch_size=c["patch"], num_frames=c["frames"], tubelet_size=c["tubelet"],
+                                      embed_dim=c["embed_dim"], predictor_embed_dim=c["pred_dim"], depth=c["pred_depth"],
+                                      num_heads=c["heads"], mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                      uniform_power=True, use_mask_tokens=True, num_mask_tokens=c["num_mask_tokens"],
+                                      zero_init_mask_tokens=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():   # non-trivial biases / LayerNorm affines / mask tokens (0 / 1 at init)
+        for mod in (enc, pred):
+            for n, p in mod.named_parameters():
+                if p.requires_grad and (p.dim() == 1 or "mask_tokens" in n):
+                    p.add_(0.05 * torch.randn(p.shape, generator=g))
+    return MultiMaskWrapper(enc), PredictorMultiMaskWrapper(pred)
+
+
+SHALLOW = [
+    # encoder head_dim 64 / predictor head_dim 32 (the ViT-L encoder's head size; HDP = 64 and 32 attention kernels)
+    dict(embed_dim=192, depth=2, heads=3, pred_dim=96, pred_depth=2, num_mask_tokens=2, crop=64, frames=8, patch=16, tubelet=2,
+         num_patches=64),
+    # predictor head_dim 24 (the step's predictor: padded head, pad-column row sums), encoder head_dim 40 (HDP = 64, ragged)
+    dict(embed_dim=120, depth=2, heads=3, pred_dim=72, pred_depth=2, num_mask_tokens=2, crop=64, frames=8, patch=16, tubelet=2,
+         num_patches=64),
+    # three blocks, head_dim 80 (ViT-H) / 128 in the predictor
+    dict(embed_dim=160, depth=3, heads=2, pred_dim=256, pred_depth=1, num_mask_tokens=2, crop=64, frames=8, patch=16, tubelet=2,
+         num_patches=64),
+]
+
+
+@pytest.mark.parametrize("ci", range(len(SHALLOW)))
+def test_shallow_models_vs_bf16_emulating_oracle(ci):
+    """Two- / three-block models of several widths and head sizes (every kernel family of the step: tubelet pack, GEMM epilogues,
+    attention forward / backward per head-dim class, LayerNorm forward / backward with column sums, gather / scatter, predictor
+    assembly, loss) against the emulating oracle.  At this depth the common-mode argument holds and the bounds are sharp."""
+    import copy
+    from oracle import vjepa_oracle as O
+    from jepa_amd.engine.step import Trainer
+    from tests.golden_util import MICRO_MASKS
+    c = SHALLOW[ci]
+    enc, pred = _build_shallow(c, 11 + ci)
+    state = dict(enc={k[len("backbone."):]: v.detach().clone() for k, v in enc.state_dict().items()},
+                 pred={k[len("backbone."):]: v.detach().clone() for k, v in pred.state_dict().items()}, opt={})
+    state["tgt"] = {k: v.clone() for k, v in state["enc"].items()}
+    tgt = copy.deepcopy(enc)
+    for p in tgt.parameters():
+        p.requires_grad = False
+    enc.to(DEV), pred.to(DEV), tgt.to(DEV)
+    tr = Trainer(enc, pred, tgt, device=DEV)
+    gens = O.make_mask_gens(MICRO_MASKS, c["crop"], c["frames"], c["patch"], c["tubelet"])
+    clips, me, mp = draw_batch(gens, 3, c, 300 + ci, 400 + ci)
+    hp = dict(HP, reg_coeff=0.0)
+    cfg = {k: c[k] for k in ("embed_dim", "depth", "heads", "pred_dim", "pred_depth", "num_mask_tokens", "patch", "tubelet", "num_patches")}
+    o32, g32 = O.step_grads(state, clips, me, mp, cfg, hp)
+    oe, ge = O.step_grads(state, clips, me, mp, cfg, hp, emu=True)
+    cd, med, mpd = to_dev(clips, me, mp)
+    h = tr.forward_target(cd, mpd)
+    with torch.no_grad():
+        zenc = enc(cd, med)
+        zpred = pred(zenc, h, med, mpd)
+    for i in range(2):
+        eh, ez, ep = rel_l2(h[i].cpu(), oe["h"][i]), rel_l2(zenc[i].float().cpu(), oe["z_enc"][i]), rel_l2(zpred[i].float().cpu(), oe["z"][i])
+        print(f"[shallow {ci}] mask {i}: h {eh:.2e} (fp32 oracle {rel_l2(h[i].cpu(), o32['h'][i]):.2e}), z_enc {ez:.2e} "
+              f"({rel_l2(zenc[i].float().cpu(), o32['z_enc'][i]):.2e}), z {ep:.2e} ({rel_l2(zpred[i].float().cpu(), o32['z'][i]):.2e})")
+        assert eh < 2e-3 and ez < 2e-3 and ep < 3e-3, (ci, i, eh, ez, ep)
+    out = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
+    _compare(tr, oe, ge, o32, g32, out, f"shallow {ci}", dict(loss=5e-5, grad=1.5e-2))
 
 
 @pytest.mark.parametrize("B", [2, 5])
 def test_tiny_step_vs_bf16_emulating_oracle(B):
-    """ViT-Tiny 8x64x64 (BASELINE configs[0]), perturbed biases / LayerNorm affines / mask tokens so that no gradient is trivially
-    zero: loss and every gradient of the arena against the emulating oracle."""
+    """ViT-Tiny 8x64x64 (BASELINE configs[0], TWELVE blocks), perturbed biases / LayerNorm affines / mask tokens.  At this depth the
+    roundings de-correlate (a value that differs by 1e-4 relative flips its bf16 rounding with probability 1e-4 / 2^-8, and the
+    attention kernels' per-tile rounding of P and the backward's recomputed P cannot be placed identically), so the emulating
+    oracle is only modestly closer than the fp32 one (measured worst gradient 3.7e-2 vs 4.2e-2): the bound is the fp32 bound."""
     from oracle import vjepa_oracle as O
     tr, state, enc, pred, tgt = build_trainer(TINY, len(TINY_MASKS), perturb_small=True)
     gens = O.make_mask_gens(TINY_MASKS, TINY["crop"], TINY["frames"], TINY["patch"], TINY["tubelet"])
@@ -97,4 +176,4 @@ def test_tiny_step_vs_bf16_emulating_oracle(B):
     oe, ge = O.step_grads(state, clips, me, mp, cfg, hp, emu=True)
     cd, med, mpd = to_dev(clips, me, mp)
     out = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
-    _compare(tr, oe, ge, o32, g32, out, f"tiny B={B}", dict(loss=2e-4, grad=2e-2))
+    _compare(tr, oe, ge, o32, g32, out, f"tiny B={B}", dict(loss=2e-4, grad=6e-2))
