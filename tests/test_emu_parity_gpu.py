@@ -113,7 +113,7 @@ SHALLOW = [
     dict(embed_dim=192, depth=2, heads=3, pred_dim=96, pred_depth=2, num_mask_tokens=2, crop=64, frames=8, patch=16, tubelet=2,
          num_patches=64),
     # predictor head_dim 24 (the step's predictor: padded head, pad-column row sums), encoder head_dim 40 (HDP = 64, ragged)
-    dict(embed_dim=120, depth=2, heads=3, pred_dim=72, pred_depth=2, num_mask_tokens=2, crop=64, frames=8, patch=16, tubelet=2,
+    dict(embed_dim=160, depth=2, heads=4, pred_dim=96, pred_depth=2, num_mask_tokens=2, crop=64, frames=8, patch=16, tubelet=2,
          num_patches=64),
     # three blocks, head_dim 80 (ViT-H) / 128 in the predictor
     dict(embed_dim=160, depth=3, heads=2, pred_dim=256, pred_depth=1, num_mask_tokens=2, crop=64, frames=8, patch=16, tubelet=2,
@@ -155,9 +155,12 @@ def test_shallow_models_vs_bf16_emulating_oracle(ci):
         eh, ez, ep = rel_l2(h[i].cpu(), oe["h"][i]), rel_l2(zenc[i].float().cpu(), oe["z_enc"][i]), rel_l2(zpred[i].float().cpu(), oe["z"][i])
         print(f"[shallow {ci}] mask {i}: h {eh:.2e} (fp32 oracle {rel_l2(h[i].cpu(), o32['h'][i]):.2e}), z_enc {ez:.2e} "
               f"({rel_l2(zenc[i].float().cpu(), o32['z_enc'][i]):.2e}), z {ep:.2e} ({rel_l2(zpred[i].float().cpu(), o32['z'][i]):.2e})")
-        assert eh < 2e-3 and ez < 2e-3 and ep < 3e-3, (ci, i, eh, ez, ep)
+        # measured (trip 15): h <= 6.8e-4, z_enc <= 9.0e-4, z <= 2.9e-3; against the fp32 oracle the same outputs sit at 5e-3 ... 6.6e-3
+        assert eh < 2e-3 and ez < 2e-3 and ep < 6e-3, (ci, i, eh, ez, ep)
     out = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
-    _compare(tr, oe, ge, o32, g32, out, f"shallow {ci}", dict(loss=5e-5, grad=1.5e-2))
+    # measured: loss 5e-6 ... 9e-6, worst gradient 1.2e-2 (patch_embed.proj.weight, the end of the backward chain), median 6e-3;
+    # fp32 oracle: worst 2.4e-2 ... 2.7e-2, median 1.6e-2
+    _compare(tr, oe, ge, o32, g32, out, f"shallow {ci}", dict(loss=5e-5, grad=2.5e-2))
 
 
 @pytest.mark.parametrize("B", [2, 5])
