@@ -4,7 +4,6 @@
 //   bf16 re-cast of both weight sets (the operands of next step's MFMA GEMMs)
 // One pass, 28 B/param of mandatory traffic + 2-4 B/param of bf16 shadows. HBM-bound.
 #include "common.hpp"
-#include "options.hpp"
 
 struct AdamArgs {
   float* p;         // master weights (fp32)
@@ -27,7 +26,6 @@ struct AdamArgs {
   const float* step_dev;  // device step counter t (already advanced by vj_step_advance); bias corrections from it
 };
 
-template <int VAR>
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   const int64_t n4 = a.n >> 2;
   bool skip = false;
@@ -66,36 +64,15 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   }
   const float step = a.lr / a.bc1;
   const float decay = 1.0f - a.lr * a.wd;
-  // VAR 0: one float4 group per thread and iteration; VAR 1 (round 4): TWO groups a grid stride apart, every load of both issued
-  // before the first use (9-10 independent 16-byte loads in flight per thread instead of 4-5); VAR 2: VAR 1 with non-temporal
-  // loads / stores on the streams nothing re-reads before the next step (gradients, moments, master weights, target).
-  // The per-element arithmetic is the same expression in every variant: bit-identical results.
-  auto ld4 = [](const float* base, int64_t q) __attribute__((always_inline)) {
-    if constexpr (VAR == 2) {
-      const float* b = base + 4 * q;
-      return make_float4(__builtin_nontemporal_load(b), __builtin_nontemporal_load(b + 1), __builtin_nontemporal_load(b + 2),
-                         __builtin_nontemporal_load(b + 3));
-    } else {
-      return ((const float4*)base)[q];
-    }
-  };
-  auto st4 = [](float* base, int64_t q, const float* v) __attribute__((always_inline)) {
-    if constexpr (VAR == 2) {
-      float* b = base + 4 * q;
-      __builtin_nontemporal_store(v[0], b);
-      __builtin_nontemporal_store(v[1], b + 1);
-      __builtin_nontemporal_store(v[2], b + 2);
-      __builtin_nontemporal_store(v[3], b + 3);
-    } else {
-      ((float4*)base)[q] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  };
-  auto update = [&](int64_t q, const float4& p4, const float4& g4, const float4& m4, const float4& v4, const float4& t4)
-                    __attribute__((always_inline)) {
-    float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    float4 p = ((float4*)a.p)[q];
+    const float4 g4 = ((const float4*)a.g)[q];
+    float4 m = ((float4*)a.m)[q];
+    float4 v = ((float4*)a.v)[q];
+    float pp[4] = {p.x, p.y, p.z, p.w};
     const float gg[4] = {g4.x * a.gscale, g4.y * a.gscale, g4.z * a.gscale, g4.w * a.gscale};
-    float mm[4] = {m4.x, m4.y, m4.z, m4.w};
-    float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    float mm[4] = {m.x, m.y, m.z, m.w};
+    float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       pp[i] *= decay;                                        // p.mul_(1 - lr*wd)
@@ -104,9 +81,9 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
       const float denom = sqrtf(vv[i]) / a.bc2_sqrt + a.eps;
       pp[i] -= step * (mm[i] / denom);
     }
-    st4(a.p, q, pp);
-    st4(a.m, q, mm);
-    st4(a.v, q, vv);
+    ((float4*)a.p)[q] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    ((float4*)a.m)[q] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    ((float4*)a.v)[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     if (a.p_bf16) {
       u32x2_t w;
       w[0] = pack_bf2(pp[0], pp[1]);
@@ -114,10 +91,11 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
       ((u32x2_t*)a.p_bf16)[q] = w;
     }
     if (a.tgt) {
+      const float4 t4 = ((float4*)a.tgt)[q];
       float tt[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
       for (int i = 0; i < 4; i++) tt[i] = tt[i] * a.ema + (1.0f - a.ema) * pp[i];
-      st4(a.tgt, q, tt);
+      ((float4*)a.tgt)[q] = make_float4(tt[0], tt[1], tt[2], tt[3]);
       if (a.tgt_bf16) {
         u32x2_t w;
         w[0] = pack_bf2(tt[0], tt[1]);
@@ -125,24 +103,6 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
         ((u32x2_t*)a.tgt_bf16)[q] = w;
       }
     }
-  };
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (VAR != 0) {
-    for (; q + stride < n4; q += 2 * stride) {
-      const int64_t q2 = q + stride;
-      const float4 p0 = ld4(a.p, q), g0 = ld4(a.g, q), m0 = ld4(a.m, q), v0 = ld4(a.v, q);
-      const float4 p1 = ld4(a.p, q2), g1 = ld4(a.g, q2), m1 = ld4(a.m, q2), v1 = ld4(a.v, q2);
-      const float4 t0 = a.tgt ? ld4(a.tgt, q) : zero4, t1 = a.tgt ? ld4(a.tgt, q2) : zero4;
-      update(q, p0, g0, m0, v0, t0);
-      update(q2, p1, g1, m1, v1, t1);
-    }
-  }
-  for (; q < n4; q += stride) {
-    const float4 p0 = ld4(a.p, q), g0 = ld4(a.g, q), m0 = ld4(a.m, q), v0 = ld4(a.v, q);
-    const float4 t0 = a.tgt ? ld4(a.tgt, q) : zero4;
-    update(q, p0, g0, m0, v0, t0);
   }
 }
 
@@ -151,14 +111,6 @@ static inline int flat_grid(int64_t n_items) {
   if (g > 256 * 8) g = 256 * 8;
   if (g < 1) g = 1;
   return (int)g;
-}
-static void launch_adamw(const AdamArgs& a, int64_t n, hipStream_t stream) {
-  const int grid = flat_grid(n / 4);
-  switch (vj_opt(VJ_OPT_ADAM_VARIANT)) {
-    case 1: hipLaunchKernelGGL(adamw_ema_kernel<1>, dim3(grid), dim3(256), 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(adamw_ema_kernel<2>, dim3(grid), dim3(256), 0, stream, a); break;
-    default: hipLaunchKernelGGL(adamw_ema_kernel<0>, dim3(grid), dim3(256), 0, stream, a);
-  }
 }
 
 extern "C" int vj_adamw_ema(float* p, const float* g, float* exp_avg, float* exp_avg_sq, void* p_bf16, float* tgt,
@@ -174,7 +126,7 @@ extern "C" int vj_adamw_ema(float* p, const float* g, float* exp_avg, float* exp
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   a.gscale = gscale; a.ema = ema;
   a.gstat = nullptr; a.sel = 0; a.clip = 0.f; a.norm_scale = 1.f; a.step_dev = nullptr;
-  launch_adamw(a, n, stream);
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, a);
   VJ_LAUNCH_CHECK("vj_adamw_ema");
   return 0;
 }
@@ -203,7 +155,7 @@ extern "C" int vj_adamw_ema_guarded(float* p, const float* g, float* exp_avg, fl
   a.tgt_bf16 = (bf16_t*)tgt_bf16; a.n = n; a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
   a.bc1 = 1.f; a.bc2_sqrt = 1.f; a.gscale = gscale; a.ema = ema;
   a.gstat = gstat; a.sel = sel; a.clip = clip; a.norm_scale = norm_scale; a.step_dev = step_dev;
-  launch_adamw(a, n, stream);
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, stream, a);
   VJ_LAUNCH_CHECK("vj_adamw_ema_guarded");
   return 0;
 }

@@ -43,8 +43,6 @@ enum VjOpt {
                                // (vj_attn_fwd_segs / vj_attn_bwd_segs); 0: one launch (pair) per segment.  Bit-identical results
   VJ_OPT_LN_BWD_PREFETCH,      // 1 (default, round 4): the LayerNorm backward requests x | dy | dres | mean | rstd of its next row before it
                                // computes the current one; 0: when the row is needed.  Bit-identical results
-  VJ_OPT_ADAM_VARIANT,         // AdamW + EMA kernel: 0 one float4 group per thread and iteration; 1 two groups, all loads first; 2 as 1 with
-                               // non-temporal loads / stores on the fp32 streams.  Bit-identical results
   VJ_OPT_COUNT
 };
 

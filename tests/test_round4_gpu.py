@@ -537,31 +537,3 @@ def test_gelu_poly_epilogue(ops, M):
     d = dg[0].cpu().double()
     assert float((d - xg.grad).abs().max()) < 5e-3        # half a bf16 ulp at 1.13 (4e-3) + the q error
     assert rel_l2(d, xg.grad) < 3e-3
-
-
-# ------------------------------------------------------------------------------------------ AdamW kernel variants
-@pytest.mark.parametrize("n,with_tgt", [(4096 + 64, True), (3 * 524288 + 4 * 77, True), (2 * 524288 + 4, False), (8, True)])
-def test_adamw_variants_are_bit_identical(ops, n, with_tgt):
-    """Option adam_variant (0: one float4 group per thread and iteration; 1: two groups, loads first; 2: + non-temporal accesses):
-    the same element-wise expression in every variant -> identical P, M1, M2, target and both bf16 shadows, for lengths below, at
-    and above one / two grid strides (2048 workgroups x 256 threads x 4 elements), with and without an EMA target."""
-    g = torch.Generator(device=DEV).manual_seed(17)
-    p0 = torch.randn(n, device=DEV, generator=g)
-    grad = torch.randn(n, device=DEV, generator=g)
-    m0 = torch.randn(n, device=DEV, generator=g) * 0.1
-    v0 = torch.rand(n, device=DEV, generator=g) * 0.01
-    t0 = torch.randn(n, device=DEV, generator=g)
-    res = []
-    for var in (0, 1, 2):
-        with _opt("adam_variant", var):
-            p, m, v, t = p0.clone(), m0.clone(), v0.clone(), t0.clone()
-            pb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
-            tb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
-            ops.adamw_ema(p, grad, m, v, pb, t if with_tgt else None, tb if with_tgt else None, 1e-3, 0.05, 0.9, 0.999, 1e-8, 3, 0.7,
-                          0.998)
-            torch.cuda.synchronize()
-            res.append((p, m, v, pb) + ((t, tb) if with_tgt else ()))
-    for var in (1, 2):
-        for a, b in zip(res[0], res[var]):
-            assert torch.equal(a, b), (var, n)
-    assert not torch.equal(res[0][0], p0)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """AdamW + EMA + bf16 re-cast kernel on ViT-L-sized arenas (304 M encoder parameters with a target, 22 M predictor parameters without):
-bytes moved / time for every value of option adam_variant."""
+bytes moved / time (the unroll-by-two and non-temporal variants of round 4 measured the same and were removed:
+profiles/r04_adam_variants.md)."""
 import os
 import sys
 
@@ -8,7 +9,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jepa_amd.hip import ops  # noqa: E402
-from jepa_amd.hip.lib import set_option  # noqa: E402
 
 
 def main():
@@ -20,8 +20,7 @@ def main():
         pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
         tb = torch.empty(n, dtype=torch.bfloat16, device=dev) if with_tgt else None
         bytes_moved = n * (4 * 4 + 3 * 4 + 2 + ((4 + 4 + 2) if with_tgt else 0))
-        for var in (0, 1, 2, 0, 1, 2):
-            set_option("adam_variant", var)
+        for var in (0, 0):
             for _ in range(2):
                 ops.adamw_ema(p, g, m, v, pb, t, tb, 1e-4, 0.05, 0.9, 0.999, 1e-8, 5, 1.0, 0.998)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,8 +30,7 @@ def main():
             e.record()
             torch.cuda.synchronize()
             us = s.elapsed_time(e) * 1e3 / 10
-            print(f"adamw n={n} target={with_tgt} variant={var}: {us:8.1f} us  {bytes_moved / us / 1e6:5.2f} TB/s", flush=True)
-        set_option("adam_variant", 0)
+            print(f"adamw n={n} target={with_tgt}: {us:8.1f} us  {bytes_moved / us / 1e6:5.2f} TB/s", flush=True)
 
 
 if __name__ == "__main__":
