@@ -180,3 +180,29 @@ def test_tiny_step_vs_bf16_emulating_oracle(B):
     cd, med, mpd = to_dev(clips, me, mp)
     out = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
     _compare(tr, oe, ge, o32, g32, out, f"tiny B={B}", dict(loss=2e-4, grad=6e-2))
+
+
+@pytest.mark.timeout(900)
+def test_vitl_step_vs_emulating_oracle_run_by_eager_pytorch_on_the_gpu():
+    """Context figure at the benched MODEL (ViT-L/16 16x224x224, 24 + 12 blocks; B = 8 because the emulation materialises the
+    [B, H, S, S] probabilities that SDPA never stores): the emulating oracle and the fp32 oracle, both run by eager PyTorch on the
+    same GPU, against the HIP step.  At this depth the emulation is expected to help little (see the ViT-Tiny case); the bound is the
+    arena-wide 3e-2 of tests/test_round2_gpu.py for both."""
+    from oracle import vjepa_oracle as O
+    from tests.step_util import VITL, VITL_MASKS
+    tr, state, _, _, _ = build_trainer(VITL, 2)
+    gens = O.make_mask_gens(VITL_MASKS, VITL["crop"], VITL["frames"], VITL["patch"], VITL["tubelet"])
+    clips, me, mp = draw_batch(gens, 8, VITL, 1234, 4321)
+    cd, med, mpd = to_dev(clips, me, mp)
+    cfg = oracle_cfg(VITL, 2)
+    st = {k: ({n: t.to(DEV) for n, t in v.items()} if k != "opt" else {}) for k, v in state.items()}
+    hp = dict(HP, reg_coeff=0.0)
+    o32, g32 = O.step_grads(st, cd, med, mpd, cfg, hp)
+    g32 = {grp: {n: t.float().cpu() for n, t in gs.items()} for grp, gs in g32.items()}
+    torch.cuda.empty_cache()
+    oe, ge = O.step_grads(st, cd, med, mpd, cfg, hp, emu=True)
+    ge = {grp: {n: t.float().cpu() for n, t in gs.items()} for grp, gs in ge.items()}
+    del st
+    torch.cuda.empty_cache()
+    out = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
+    _compare(tr, oe, ge, o32, g32, out, "ViT-L B=8", dict(loss=1e-3, grad=3e-2))
