@@ -45,6 +45,9 @@ def _compare(tr, o_emu, g_emu, o_f32, g_f32, out, tag, bounds):
           f"five worst: {[(round(a, 5), n) for a, _, n in per[:5]]}")
     assert res["loss"] < bounds["loss"], (tag, res)
     assert worst < bounds["grad"], (tag, res, per[:5])
+    if "grad_rest" in bounds:   # every tensor except the named ones against a tighter bound
+        rest = [x for x in per if x[2] not in bounds["except"]]
+        assert rest[0][0] < bounds["grad_rest"], (tag, rest[:5])
     return res
 
 
@@ -186,8 +189,9 @@ def test_tiny_step_vs_bf16_emulating_oracle(B):
 def test_vitl_step_vs_emulating_oracle_run_by_eager_pytorch_on_the_gpu():
     """Context figure at the benched MODEL (ViT-L/16 16x224x224, 24 + 12 blocks; B = 8 because the emulation materialises the
     [B, H, S, S] probabilities that SDPA never stores): the emulating oracle and the fp32 oracle, both run by eager PyTorch on the
-    same GPU, against the HIP step.  At this depth the emulation is expected to help little (see the ViT-Tiny case); the bound is the
-    arena-wide 3e-2 of tests/test_round2_gpu.py for both."""
+    same GPU, against the HIP step.  With thousands of rows per tensor the de-correlated part of the rounding noise averages out and the
+    emulation helps again: measured (trip 17) loss 2.9e-7 (fp32 oracle 3.4e-5), gradients median 2.0e-3 (7.8e-3), every tensor <= 3.4e-3
+    except patch_embed.proj.weight, the end of the backward chain, at 1.1e-2 (1.3e-2)."""
     from oracle import vjepa_oracle as O
     from tests.step_util import VITL, VITL_MASKS
     tr, state, _, _, _ = build_trainer(VITL, 2)
@@ -205,4 +209,4 @@ def test_vitl_step_vs_emulating_oracle_run_by_eager_pytorch_on_the_gpu():
     del st
     torch.cuda.empty_cache()
     out = tr.train_step(cd, med, mpd, lr=0.0, wd=0.0, ema=1.0)
-    _compare(tr, oe, ge, o32, g32, out, "ViT-L B=8", dict(loss=1e-3, grad=3e-2))
+    _compare(tr, oe, ge, o32, g32, out, "ViT-L B=8", dict(loss=2e-5, grad=2.5e-2, grad_rest=7e-3, **{"except": ("enc.patch_embed.proj.weight",)}))
