@@ -91,12 +91,6 @@ int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
                     void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags,
                     vj_stream_t stream);
-/* EXPERIMENT of round 4 (csrc/gemm1w.hip; tools and tests only, never called by the training path): the same product with ONE wave per
- * SIMD (four waves of 128 x 128, MFMA 32x32x16, fragment reads / LDS-DMA / one barrier per 32-wide K-tile under back-to-back MFMAs) and a
- * plain epilogue (bias, residual).  M, N >= 256, K % 32 == 0.  dbg bit0: no output traffic (K-sweep of the K loop alone).  Replaces
- * nothing in the reference; it measures what the section structure of the production kernels costs. */
-int vj_gemm_bf16_nt_1w(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                       const float* bias, const void* residual, int64_t ldr, int dbg, vj_stream_t stream);
 /* fc2 dgrad (epilogue 2) that also produces the bias gradient of fc1 (autograd of Mlp.fc1's bias, modules.py:31-34: the sum
  * over tokens of the dY this GEMM writes): when the persistent 256 x 256 kernel takes the problem, colpart
  * [vj_gemm_colsum_rows(M)][N] receives fp32 column sums of C (before the bf16 rounding) per (row tile, wave row) and *fused = 1;

@@ -61,7 +61,6 @@ SIGNATURES = {
     "vj_layernorm_bwd_colsum": (I32, [P, P, P, P, P, P, P, P, P, P, F32, F32, I64, I64, P, I64, P]),
     "vj_gemm_bf16_nt": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, P, P, I64, I32, F32, F32, I32, P]),
     "vj_gemm_colsum_rows": (I64, [I64]),
-    "vj_gemm_bf16_nt_1w": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, P, P, I64, I32, P]),
     "vj_gemm_bf16_nt_dgelu_colsum": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, P, I64, P, I64, I32, ctypes.POINTER(I32), P]),
     "vj_gemm_bf16_nt_splitk": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, F32, F32, I32, P, I64, P]),
     "vj_gemm_bf16_tn_splitk": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, F32, F32, P, I64, P]),

@@ -416,22 +416,6 @@ def gemm_dgelu_colsum(dy, wT, aux_in, stream=None):
     return du, (colpart if fused.value else None)
 
 
-def gemm_nt_1w(a, w, bias=None, residual=None, out=None, dbg=0, stream=None):
-    """EXPERIMENT (csrc/gemm1w.hip, not on the training path): C = a w^T (+ bias, + residual) with one wave per SIMD and MFMA
-    32x32x16.  M, N >= 256, K % 32 == 0."""
-    lib = load_library()
-    _req(a, BF16, "a")
-    _req(w, BF16, "w")
-    M, K = a.shape
-    N = w.shape[0]
-    if out is None:
-        out = torch.empty((M, N), dtype=BF16, device=a.device)
-    check(lib.vj_gemm_bf16_nt_1w(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), M, N, K, _ptr(bias),
-                                 _ptr(residual), residual.stride(0) if residual is not None else 0, dbg, _stream(stream)),
-          "vj_gemm_bf16_nt_1w")
-    return out
-
-
 def reduce_segments(segs, alpha=1.0, accumulate=False, stream=None):
     """segs: list of (part fp32 [P, stride] (a 2-D tensor or a column slice of one), out fp32 [N]) -> out = alpha * column sums
     (+ old when accumulating), all in ONE launch (vj_reduce_segments)."""

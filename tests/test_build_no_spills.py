@@ -28,9 +28,7 @@ def test_no_kernel_spills_vector_registers():
     for base, text in outs:
         for name, spill in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
             n_kernels += 1
-            # (the EXPERIMENTAL one-wave-per-SIMD GEMM of round 4 -- 256 accumulators + fragments, never on the training path --
-            #  spills four registers in its EPILOGUE; its K loop, which is what it measures, holds ~100 of its 256 vector registers)
-            if int(spill) != 0 and "gemm_nt_1w_kernel" not in name:
+            if int(spill) != 0:
                 offenders.append((base, name, int(spill)))
     assert n_kernels >= 100, n_kernels          # 106 kernels at the end of round 3
     assert not offenders, offenders

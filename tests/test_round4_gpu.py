@@ -537,30 +537,3 @@ def test_gelu_poly_epilogue(ops, M):
     d = dg[0].cpu().double()
     assert float((d - xg.grad).abs().max()) < 5e-3        # half a bf16 ulp at 1.13 (4e-3) + the q error
     assert rel_l2(d, xg.grad) < 3e-3
-
-
-# ------------------------------------------------------------------------------------------ experimental one-wave-per-SIMD GEMM
-@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (512, 768, 96), (1000, 520, 64), (2049, 1024, 1024), (10560, 1024, 4096),
-                                   (4096, 4096, 160)])
-def test_experimental_one_wave_per_simd_gemm(ops, M, N, K):
-    """csrc/gemm1w.hip (EXPERIMENT, never on the training path): four waves of 128 x 128 with MFMA 32x32x16, four 32-wide K stages,
-    fragment reads / LDS-DMA issued under back-to-back MFMAs.  Against the fp32 product (rel-L2 4e-3, the bound of the production
-    GEMMs) and against the production kernel (same operands; a different MFMA shape sums K in a different order, so agreement is to
-    bf16 rounding, not bitwise): plain, with bias, with bias + residual; one K stage, fewer K-tiles than pipeline stages, shifted
-    edge tiles in M and N; three draws."""
-    for seed in range(3):
-        g = torch.Generator(device=DEV).manual_seed(900 + seed)
-        A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
-        W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
-        bias = torch.randn(N, device=DEV, generator=g)
-        res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
-        ref = A.float() @ W.float().t()
-        for kw, r in ((dict(), ref), (dict(bias=bias), ref + bias), (dict(bias=bias, residual=res), ref + bias + res.float())):
-            out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
-            ops.gemm_nt_1w(A, W, out=out, **kw)
-            torch.cuda.synchronize()
-            assert not torch.isnan(out.float()).any(), (seed, sorted(kw), "unwritten output")
-            assert rel_l2(out, r) < 4e-3, (seed, sorted(kw), rel_l2(out, r))
-            prod = ops.gemm_nt(A, W, **kw)
-            frac = float((out != prod).float().mean())
-            assert frac < 0.05 and rel_l2(out, prod) < 2e-3, (seed, sorted(kw), frac)   # one-ulp flips of the bf16 rounding only
