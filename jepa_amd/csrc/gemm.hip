@@ -354,6 +354,7 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.zero_row = nullptr;
   a.colpart = nullptr;
   a.gelu_lp = vj_opt(VJ_OPT_GELU_POLY);
+  a.raster = 0;
   a.qscale = qscale;
   a.qcols = qscale != 0.f ? N / 3 : 0;
   switch (epilogue) {
@@ -404,6 +405,7 @@ extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const vo
     a.qcols = 0;
     a.colpart = colpart;
     a.gelu_lp = 0;
+    a.raster = 0;
     const int rc = vj_gemm_launch_8phase_persist(a, EPI_DGELU, stream);
     if (rc != -100) {
       *fused = (rc == 0);

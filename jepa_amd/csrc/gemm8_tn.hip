@@ -154,6 +154,7 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
   GemmArgs p;
   p.colpart = nullptr;
   p.gelu_lp = 0;
+  p.raster = 0;
   p.qscale = 0.f;
   p.qcols = 0;
   int logical_all;
@@ -410,6 +411,7 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
   GemmArgs b;
   b.colpart = nullptr;
   b.gelu_lp = 0;
+  b.raster = 0;
   b.qscale = 0.f;
   b.qcols = 0;
   b.A = (const bf16_t*)dY; b.B = (const bf16_t*)X; b.C = dW; b.bias = nullptr; b.res = nullptr; b.aux_in = nullptr;

@@ -80,7 +80,7 @@ __device__ __forceinline__ void pp_make_bases(PpBases& pb, const char* a0, const
 // logical tile index -> shifted tile origin (always a full 256 x 256 tile inside the matrix)
 __device__ __forceinline__ void pp_tile_origin(const GemmArgs& p, int logical, int64_t& m0, int64_t& n0, int& tm) {
   int tn;
-  tile_of(logical, p.tiles_m, p.tiles_n, tm, tn);
+  tile_of_raster(logical, p.tiles_m, p.tiles_n, p.raster, tm, tn);
   m0 = (int64_t)tm * 256;
   n0 = (int64_t)tn * 256;
   m0 = m0 + 256 <= p.M ? m0 : p.M - 256;
@@ -472,6 +472,7 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   b.splitk = 1;
   b.ws = nullptr;
   b.ktiles_per = (int)(a.K / 64);
+  b.raster = vj_opt(VJ_OPT_GEMM_RASTER);
   const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
   // Grid: the tile count is fixed, so the kernel takes `rounds` = ceil(tiles / CUs) tile times whatever the grid is; the
   // SMALLEST grid that still needs only `rounds` tiles per workgroup leaves the other CUs to the step's second stream for

@@ -25,6 +25,7 @@ struct GemmArgs {
   int64_t qcols;       //   of a qkv projection carries the soft-max scale scale*log2(e): ONE rounding of c*q, attention.hip); qcols % 4 == 0
   float* colpart;      // EPI_DGELU on the persistent kernel, nullable: fp32 column-sum partials of the OUTPUT, [2 * tiles_m][N]
                        // (row slot = 2 * row tile + wave row): the bias gradient of the Linear whose dY this GEMM produces
+  int raster;          // persistent kernel: tile order (tile_of_raster; 0 = the default 8-row groups)
   int gelu_lp;         // EPI_GELU: != 0 -> Phi(-|x|) = exp2(degree-6 polynomial) (common.hpp, option gelu_poly); 0 -> A-S 7.1.26
 };
 
@@ -488,6 +489,28 @@ __device__ __forceinline__ int xcd_logical(int bid, int nblk) {
   return (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + pos;
 }
 // GM row-tiles form a group that sweeps all column tiles (keeps the A panel hot in L2)
+// raster (persistent kernel only, option gemm_raster): bits 0-7 = group size G (0 -> 8); bit 8 clear = G ROW tiles sweep all column tiles,
+// row tile fastest (the default: 32 consecutive tiles = 8 rows x 4 columns, the A panels are revisited column step after column step);
+// bit 8 set = G COLUMN tiles sweep all row tiles, column tile fastest (32 consecutive tiles = 8 rows x 4 columns again, but an XCD's band
+// now walks DOWN the rows of one column group: its B panels stay in the L2 while the A panels stream through once per column group)
+__device__ __forceinline__ void tile_of_raster(int logical, int tiles_m, int tiles_n, int raster, int& tm, int& tn) {
+  const int G = (raster & 0xff) ? (raster & 0xff) : 8;
+  if (raster & 0x100) {
+    const int per_group = G * tiles_m;
+    const int group = logical / per_group, in_g = logical - group * per_group;
+    const int first_n = group * G;
+    const int gsz = (tiles_n - first_n) < G ? (tiles_n - first_n) : G;
+    tn = first_n + in_g % gsz;
+    tm = in_g / gsz;
+  } else {
+    const int per_group = G * tiles_n;
+    const int group = logical / per_group, in_g = logical - group * per_group;
+    const int first_m = group * G;
+    const int gsz = (tiles_m - first_m) < G ? (tiles_m - first_m) : G;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
+}
 __device__ __forceinline__ void tile_of(int logical, int tiles_m, int tiles_n, int& tm, int& tn) {
   constexpr int GM = 8;
   const int per_group = GM * tiles_n;

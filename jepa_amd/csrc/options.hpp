@@ -43,6 +43,8 @@ enum VjOpt {
                                // (vj_attn_fwd_segs / vj_attn_bwd_segs); 0: one launch (pair) per segment.  Bit-identical results
   VJ_OPT_LN_BWD_PREFETCH,      // 1 (default, round 4): the LayerNorm backward requests x | dy | dres | mean | rstd of its next row before it
                                // computes the current one; 0: when the row is needed.  Bit-identical results
+  VJ_OPT_GEMM_RASTER,          // tile order of the persistent NT GEMM (gemm_common.hpp tile_of_raster): bits 0-7 group size (0 = 8), bit 8 = groups of
+                               // COLUMN tiles walking down the rows instead of groups of row tiles sweeping the columns.  Bit-identical results
   VJ_OPT_COUNT
 };
 

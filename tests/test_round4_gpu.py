@@ -537,3 +537,35 @@ def test_gelu_poly_epilogue(ops, M):
     d = dg[0].cpu().double()
     assert float((d - xg.grad).abs().max()) < 5e-3        # half a bf16 ulp at 1.13 (4e-3) + the q error
     assert rel_l2(d, xg.grad) < 3e-3
+
+
+# ------------------------------------------------------------------------------------------ tile order of the persistent GEMM
+@pytest.mark.parametrize("M,N,K", [(8192 + 77, 2304, 512), (10560, 3072, 1088), (37632, 1024, 256), (58560, 384, 1536)])
+def test_persistent_gemm_tile_orders_are_bit_identical(ops, M, N, K):
+    """Option gemm_raster (group size, row- or column-grouped tile order of gemm8p.hip): a different ORDER of the same tiles -> the same bits,
+    for the plain / residual / GELU epilogues and for the fc2-dgrad epilogue with its column partials (whose slot is the row tile)."""
+    g = torch.Generator(device=DEV).manual_seed(41)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    aux = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(torch.bfloat16)
+
+    def run_all():
+        outs = [ops.gemm_nt(A, W, bias=bias), ops.gemm_nt(A, W, bias=bias, residual=res), ops.gemm_nt(A, W, bias=bias, epilogue=ops.EPI_GELU)]
+        du, colpart = ops.gemm_dgelu_colsum(A, W, aux)
+        outs.append(du)
+        if colpart is not None:
+            outs.append(colpart.sum(dim=0))
+        torch.cuda.synchronize()
+        return outs
+    with _opt("gemm_raster", 0):
+        ref = run_all()
+    for raster in (4, 16, 2, 256 + 4, 256 + 2, 256 + 8):
+        with _opt("gemm_raster", raster):
+            got = run_all()
+        for i, (a, b) in enumerate(zip(ref, got)):
+            if a.dtype == torch.float32:   # column sums: the same partial rows, summed here by torch (order-independent to 1e-6)
+                assert rel_l2(b, a) < 1e-6, (raster, i)
+            else:
+                assert torch.equal(a, b), (raster, i, int((a != b).sum()))
