@@ -473,15 +473,8 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   b.ws = nullptr;
   b.ktiles_per = (int)(a.K / 64);
   b.raster = vj_opt(VJ_OPT_GEMM_RASTER);
-  if (b.raster == 511) {   // automatic: column groups of the largest divisor of the column-tile count that is <= 6 (none >= 3: groups of 4)
-    int gsel = 4;
-    for (int d = 6; d >= 2; d--)
-      if (b.tiles_n % d == 0) {
-        gsel = d;
-        break;
-      }
-    if (b.tiles_n <= 6) gsel = b.tiles_n;
-    b.raster = 256 + gsel;
+  if (b.raster == 511) {   // automatic: column groups of six for the encoder shapes (K >= 1024), the row-grouped order for the short-K predictor shapes
+    b.raster = a.K >= 1024 ? 256 + 6 : 0;
   }
   const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
   // Grid: the tile count is fixed, so the kernel takes `rounds` = ceil(tiles / CUs) tile times whatever the grid is; the
