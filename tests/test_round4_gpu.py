@@ -561,7 +561,7 @@ def test_persistent_gemm_tile_orders_are_bit_identical(ops, M, N, K):
         return outs
     with _opt("gemm_raster", 0):
         ref = run_all()
-    for raster in (4, 16, 2, 256 + 4, 256 + 2, 256 + 8):
+    for raster in (4, 16, 2, 256 + 4, 256 + 2, 256 + 8, 256 + 6, 256 + 3, 511):
         with _opt("gemm_raster", raster):
             got = run_all()
         for i, (a, b) in enumerate(zip(ref, got)):
