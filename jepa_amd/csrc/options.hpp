@@ -44,7 +44,11 @@ enum VjOpt {
   VJ_OPT_LN_BWD_PREFETCH,      // 1 (default, round 4): the LayerNorm backward requests x | dy | dres | mean | rstd of its next row before it
                                // computes the current one; 0: when the row is needed.  Bit-identical results
   VJ_OPT_GEMM_RASTER,          // tile order of the persistent NT GEMM (gemm_common.hpp tile_of_raster): bits 0-7 group size (0 = 8), bit 8 = groups of
-                               // COLUMN tiles walking down the rows instead of groups of row tiles sweeping the columns.  Bit-identical results
+                               // COLUMN tiles walking down the rows instead of groups of row tiles sweeping the columns; 511 = column groups of six for
+                               // K >= 1024, the row-grouped order otherwise.  Default 260 (late round 4): column groups of FOUR -- an XCD's 32 concurrent tiles
+                               // are still 8 rows x 4 columns, but its band walks down the rows of one column group, so the B panels stay in its L2 and
+                               // every A panel streams through once per column group: fabric reads of the encoder shapes -14 ... -38 %, step -0.6 ... -0.8 ms
+                               // (profiles/r04_gemm_raster.md).  0 = the order of rounds 2-4 (groups of 8 row tiles).  Bit-identical results
   VJ_OPT_COUNT
 };
 
