@@ -312,6 +312,10 @@ int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads);
  * in one vj_gemm_bf16_tn_grouped launch once the block's last dY exists).
  * flags bit1: the caller already wrote the LAST block's fc2 bias gradient (the column sums of dout; it comes out of the
  * LayerNorm backward that produced dout, vj_layernorm_bwd_colsum) -- with the transpose-free route only.
+ * flags bits 2-3: bit 3 set = "bit 2 tells whether the forward stored q pre-scaled by scale*log2(e)" (what vj_blocks_fwd does under
+ * option "attn_softmax" = 2 when D % 4 == 0); callers record the convention at forward time and pass it here, so that an option change
+ * between a forward and its backward cannot make the backward read the saved qkv with the wrong convention.  Bit 3 clear: the option is
+ * read again at backward time (only right if it did not change).
  * With the transpose-free route and option "bias_fuse" (default) the bias gradients of qkv and fc1 come from column partials of
  * the kernels that produce dqkv / du (vj_attn_bwd_colsum, vj_gemm_bf16_nt_dgelu_colsum) and every partial reduction of a block
  * (both LayerNorms', those two) is ONE vj_reduce_segments launch at the end of the block. */
@@ -347,7 +351,7 @@ int vj_comm_destroy(vj_comm_t comm);
  * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
  * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_tn",
  * "wgrad_group", "wgrad_slow_issue", "attn_dkdv_kt", "gemm_dbg", "attn_softmax", "bias_fuse", "gelu_poly", "gemm_sched", "attn_psum",
- * "attn_merge" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * "attn_merge", "ln_bwd_prefetch", "gemm_raster" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
  * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
 int vj_set_option(const char* name, int value);
 int vj_get_option(const char* name, int* value);

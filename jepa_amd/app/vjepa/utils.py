@@ -102,7 +102,15 @@ def init_opt(encoder, predictor, iterations_per_epoch, start_lr, ref_lr, warmup,
     Extra keyword arguments (target_encoder, loss_exp, reg_coeff, clip_grad, world_size) configure the step; gradient
     non-finite checks (GradScaler's skip semantics) are always on and device-side."""
     if target_encoder is None:
-        raise ValueError("init_opt needs target_encoder=: the EMA update is fused into the optimizer kernel")
+        # reference-compatible call (app/vjepa/utils.py:156-170 has no such argument): the EMA update is fused into the
+        # optimizer kernel, so the optimizer owns the target.  Built exactly as train.py:276-277 builds it (a deep copy of
+        # the freshly initialised encoder, frozen) and exposed as `optimizer.target_encoder`; a caller that keeps its own
+        # copy.deepcopy(encoder) must use this one instead -- the fused update writes only here.
+        import copy
+        target_encoder = copy.deepcopy(encoder)
+        for p in target_encoder.parameters():
+            p.requires_grad = False
+        logger.info('init_opt: no target_encoder= given; the EMA target is optimizer.target_encoder (deep copy of encoder)')
     optimizer = Trainer(encoder, predictor, target_encoder, loss_exp=loss_exp, reg_coeff=reg_coeff, betas=betas,
                         eps=eps, clip_grad=clip_grad, world_size=world_size, device=device, micro_batch=micro_batch)
     scheduler = WarmupCosineSchedule(optimizer, warmup_steps=int(warmup * iterations_per_epoch), start_lr=start_lr,

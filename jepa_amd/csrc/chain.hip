@@ -514,7 +514,10 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
     }
     int64_t off_q = 0, off_kv = 0;
     const bool merge_segs = n_segs > 1 && n_segs <= 4 && vj_opt(VJ_OPT_ATTN_MERGE) != 0;
-    const float ascale = (vj_opt(VJ_OPT_ATTN_SOFTMAX) == 2 && (3 * D) % 12 == 0) ? -scale : scale;   // as the forward stored q
+    // as the FORWARD stored q: flags bit 3 set -> bit 2 says whether q is pre-scaled (the caller recorded the mode its vj_blocks_fwd
+    // call used); otherwise the option is read again, which is only right if it did not change since that forward
+    const bool qpre_b = (flags & 8) ? (flags & 4) != 0 : (vj_opt(VJ_OPT_ATTN_SOFTMAX) == 2 && (3 * D) % 12 == 0);
+    const float ascale = qpre_b ? -scale : scale;
     if (merge_segs) {   // one dQ + one dK/dV launch for all segments (partials: segment after segment, as the loop below lays them out)
       double fl = 0;
       int64_t smax = 0;

@@ -41,14 +41,24 @@ const Rccl& rccl() {
     struct Found { char path[1024]; } found = {{0}};
     dl_iterate_phdr(
         [](struct dl_phdr_info* info, size_t, void* data) -> int {
-          if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) {
+          // the BASENAME must be librccl.so[.N...]: plugin objects such as librccl-net.so also contain "librccl"
+          if (!info->dlpi_name) return 0;
+          const char* base = strrchr(info->dlpi_name, '/');
+          base = base ? base + 1 : info->dlpi_name;
+          if (strncmp(base, "librccl.so", 10) == 0 && (base[10] == 0 || base[10] == '.')) {
             strncpy(((Found*)data)->path, info->dlpi_name, sizeof(Found::path) - 1);
             return 1;
           }
           return 0;
         },
         &found);
-    if (found.path[0]) g_rccl.h = dlopen(found.path, RTLD_NOW | RTLD_NOLOAD);
+    if (found.path[0]) {
+      g_rccl.h = dlopen(found.path, RTLD_NOW | RTLD_NOLOAD);
+      if (g_rccl.h && !dlsym(g_rccl.h, "ncclGetUniqueId")) {   // not an RCCL runtime after all: fall through to the names below
+        dlclose(g_rccl.h);
+        g_rccl.h = nullptr;
+      }
+    }
     for (const char* n : names) {
       if (g_rccl.h) break;
       g_rccl.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);

@@ -22,13 +22,18 @@
 //
 // Split-K over the token tiles and the fp32 epilogue are shared with the NT kernels (gemm_common.hpp).
 #include <type_traits>
-#include <mutex>
 #include "gemm_common.hpp"
 #include "options.hpp"
 
 #define TN_PART_BYTES 16384
 
 namespace {
+
+// 128 bf16 zeros: the LDS-DMA source of token rows beyond T (the last, partial token tile).  A zero-initialised device global:
+// it exists on every device the code object is loaded on, needs no allocation, no lock and no synchronisation on first use
+// (the round-4 host-allocated buffer took a global mutex per launch and a device-wide synchronise on first use, which would
+// have invalidated a stream capture in progress).
+__device__ __attribute__((aligned(256))) bf16_t g_tn_zero_row[128];
 
 __device__ __forceinline__ void tn_cfence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ void tn_bar() {
@@ -93,7 +98,7 @@ __device__ __forceinline__ void tn_issue_part(const GemmArgs& p, int q, int64_t 
     const int rowc = row < last_row ? row : last_row;
     const bf16_t* src = base + (int64_t)(int)(__umul24((unsigned)rowc, ld) + rel);
     if (isA) {
-      const bf16_t* zsrc = p.zero_row + tl.sc8;
+      const bf16_t* zsrc = g_tn_zero_row + tl.sc8;
       src = row <= last_row ? src : zsrc;
     }
     tn_dma16(src, tn_lds_addr(slot + (j * 512 + wave_u * 64) * 16));
@@ -365,34 +370,10 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
                                          slice);
 }
 
-bf16_t* g_zero_rows[VJ_MAX_DEVICES] = {};   // 128 bf16 zeros, one buffer per device
-
 }  // namespace
 
 __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, int64_t N, int64_t ldc, int S,
                                      float alpha, float beta);   // gemm.hip
-
-static int tn_zero_row(const bf16_t** out) {
-  // one buffer per device, set up once per device under a mutex (two host threads must not both allocate); the memset
-  // is followed by a device synchronise so that it is ordered before ANY stream's first TN launch (hipMemset runs on the
-  // legacy null stream, which non-blocking side streams do not wait for)
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
-  bf16_t*& z = g_zero_rows[vj_device_slot()];
-  if (z == nullptr) {
-    bf16_t* q = nullptr;
-    hipError_t e = hipMalloc((void**)&q, 256);
-    if (e == hipSuccess) e = hipMemset(q, 0, 256);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) {
-      vj_set_error("vj_gemm_bf16_tn_splitk: zero row allocation failed: %s", hipGetErrorString(e));
-      return (int)e;
-    }
-    z = q;
-  }
-  *out = z;
-  return 0;
-}
 
 static int tn_check(const char* who, const void* dY, int64_t ldy, const void* X, int64_t ldx, const float* dW, int64_t ldw,
                     int64_t T, int64_t N1, int64_t N2) {
@@ -421,7 +402,7 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
   b.tiles_m = (int)cdiv64(N1, 256);
   b.tiles_n = (int)cdiv64(N2, 256);
   b.dbg = vj_opt(VJ_OPT_WGRAD_SLOW_ISSUE) ? 8 : 0;   // A/B switch of the K loop's issue path
-  b.zero_row = nullptr;   // set by the caller (tn_zero_row)
+  b.zero_row = nullptr;   // (the TN kernel reads the zero-initialised device global g_tn_zero_row)
   b.splitk = 1;
   b.ktiles_per = (int)cdiv64(T, 64);
   b.ws = nullptr;
@@ -453,13 +434,10 @@ extern "C" int vj_gemm_bf16_tn_splitk(const void* dY, int64_t ldy, const void* X
   if (N1 == 0 || N2 == 0) return 0;
   if (int rc = tn_check("vj_gemm_bf16_tn_splitk", dY, ldy, X, ldx, dW, ldw, T, N1, N2)) return rc;
   VJ_CHECK_ARG(ws != nullptr && ws_bytes >= N1 * N2 * 4, "vj_gemm_bf16_tn_splitk: workspace must hold at least N1*N2 fp32");
-  const bf16_t* zero_row = nullptr;
-  if (int rc = tn_zero_row(&zero_row)) return rc;
   tn_set_attr<false>();
   TnSingleArgs a;
   GemmArgs& b = a.g;
   b = tn_args(dY, ldy, X, ldx, dW, ldw, T, N1, N2, alpha, beta);
-  b.zero_row = zero_row;
   const int nk = (int)cdiv64(T, 64);
   b.splitk = pick_splitk((int64_t)b.tiles_m * b.tiles_n, nk, 256, 1.45, 8, N1, N2, ws_bytes);
   b.ws = (float*)ws;
@@ -505,9 +483,6 @@ extern "C" int vj_gemm_bf16_tn_grouped(const void* probs_v, int64_t n, int64_t T
     a.n++;
   }
   if (a.n == 0) return 0;
-  const bf16_t* zero_row = nullptr;
-  if (int rc = tn_zero_row(&zero_row)) return rc;
-  for (int i = 0; i < a.n; i++) a.g[i].zero_row = zero_row;
   VJ_CHECK_ARG(ws != nullptr && ws_bytes >= out_elems * 4, "vj_gemm_bf16_tn_grouped: workspace must hold at least sum N1*N2 fp32");
   const int nk = (int)cdiv64(T, 64);
   // one split factor for the group: pick_splitk's cost model on the summed tile count / output size

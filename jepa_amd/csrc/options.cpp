@@ -12,6 +12,11 @@ struct OptDef {
   const char* name;
   int dflt, lo, hi;   // accepted range (inclusive): a value outside it is rejected, never silently mapped to some kernel
 };
+// values inside [lo, hi] that still select nothing (gemm_sched: only the 4- and the 8-section kernels exist)
+bool in_set(int id, int v) {
+  if (id == VJ_OPT_GEMM_SCHED) return v == 4 || v == 8;
+  return true;
+}
 const OptDef kDefs[VJ_OPT_COUNT] = {
     {"gemm_fwd_flags", 0, 0, 0xffff}, {"gemm_dgrad_flags", 0, 0, 0xffff}, {"gemm_4w", 0, 0, 2},
     {"gemm_persist", 1, 0, 2},        {"wgrad_tn", 1, 0, 1},              {"wgrad_group", 1, 0, 1},
@@ -30,7 +35,7 @@ void init_once() {
       for (const char* c = kDefs[i].name; *c; c++) env.push_back((char)toupper((unsigned char)*c));
       const char* e = getenv(env.c_str());
       int v = e ? atoi(e) : kDefs[i].dflt;
-      if (v < kDefs[i].lo || v > kDefs[i].hi) {
+      if (v < kDefs[i].lo || v > kDefs[i].hi || !in_set(i, v)) {
         fprintf(stderr, "libvjepa_hip: %s=%d outside [%d, %d], using the default %d\n", env.c_str(), v, kDefs[i].lo,
                 kDefs[i].hi, kDefs[i].dflt);
         v = kDefs[i].dflt;
@@ -57,8 +62,8 @@ extern "C" int vj_set_option(const char* name, int value) {
   init_once();
   const int i = find(name);
   VJ_CHECK_ARG(i >= 0, "vj_set_option: unknown option '%s'", name ? name : "(null)");
-  VJ_CHECK_ARG(value >= kDefs[i].lo && value <= kDefs[i].hi, "vj_set_option: %s=%d outside [%d, %d]", name, value,
-               kDefs[i].lo, kDefs[i].hi);
+  VJ_CHECK_ARG(value >= kDefs[i].lo && value <= kDefs[i].hi && in_set(i, value),
+               "vj_set_option: %s=%d outside [%d, %d] or not a value the option defines", name, value, kDefs[i].lo, kDefs[i].hi);
   g_val[i].store(value, std::memory_order_relaxed);
   return 0;
 }

@@ -23,10 +23,13 @@ enum VjOpt {
   VJ_OPT_WGRAD_SLOW_ISSUE,     // 1: the TN kernel's K loop issues its parts through the generic address path (A/B only)
   VJ_OPT_ATTN_DKDV_KT,         // 16-key tiles per wave in the attention dK/dV kernel: 0 (default) per head-dim class, 1 / 2 forced
   VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)
-  VJ_OPT_ATTN_SOFTMAX,         // 1 (default, round 4): attention kernels with the soft-max scale folded into the stationary operand
-                               // and the score accumulators seeded with -max / -lse (no per-score FMA, no per-tile row maximum);
+  VJ_OPT_ATTN_SOFTMAX,         // 1 (A/B only): attention kernels with the soft-max scale folded into the stationary operand
+                               // and the score accumulators seeded with -max / -lse (no per-score FMA, no per-tile row maximum).  With a
+                               // positive scale the forward / dQ kernels fold c into Q and dK/dV folds it into K: the backward's scores
+                               // then differ from the ones lse2 was built from by one bf16 rounding of the operand (2^-9 |s|), so mode 1
+                               // is for measurements, not for training;
                                // 0: the round-3 kernels (results agree to bf16 rounding, not bitwise);
-                               // 2: as 1, but inside the block chains the scale reaches q in the qkv GEMM's epilogue (vj_gemm_bf16_nt
+                               // 2 (DEFAULT since round 4): as 1, but inside the block chains the scale reaches q in the qkv GEMM's epilogue (vj_gemm_bf16_nt
                                // epilogue 4: one rounding of c*q, no second rounding of the stationary operand) and the attention
                                // entry points are told so through a NEGATIVE scale argument
   VJ_OPT_BIAS_FUSE,            // 1 (default, round 4): qkv / fc1 bias gradients from column partials written by the kernels that
@@ -35,7 +38,7 @@ enum VjOpt {
   VJ_OPT_GELU_POLY,            // 1 (default, round 4): the GELU epilogues take Phi(-|x|) as exp2 of a degree-6 polynomial in min(|x|, 5)
                                // (6 FMAs + the one v_exp; no v_rcp, three multiplies fewer; closer to the correctly rounded bf16 erf-GELU
                                // than 0:) Abramowitz-Stegun 7.1.26.  Results agree to one bf16 ulp on < 0.2 % of the inputs, not bitwise
-  VJ_OPT_GEMM_SCHED,           // load / compute section pairs per K-tile of the persistent NT GEMM: 8 = four pairs of 16 MFMAs (round 3),
+  VJ_OPT_GEMM_SCHED,           // (values 4 and 8 only) load / compute section pairs per K-tile of the persistent NT GEMM: 8 = four pairs of 16 MFMAs (round 3),
                                // 4 = two pairs of 32 MFMAs (round 4: half the section boundaries); bit-identical results
   VJ_OPT_ATTN_PSUM,            // 1 (default): the forward takes its soft-max row sums from the matrix pipe (head_dim 24: the V pad column of
                                // the P.V MFMA; other head sizes: an all-ones operand, two extra MFMAs per key tile); 0: vector adds

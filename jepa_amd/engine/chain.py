@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from ..hip.lib import LAYER_CB, VjBlock, VjLinear, VjNorm, VjSeg, check, load_library
+from ..hip.lib import LAYER_CB, VjBlock, VjLinear, VjNorm, VjSeg, check, get_option, load_library
 
 
 def _p(t):
@@ -74,10 +74,11 @@ class Workspace:
 
 class TrunkCtx:
     """What `blocks_backward` needs from `blocks_forward`."""
-    __slots__ = ("x_in", "ws", "M", "D", "segs", "seg_arr")
+    __slots__ = ("x_in", "ws", "M", "D", "segs", "seg_arr", "qpre")
 
-    def __init__(self, x_in, ws, M, D, segs, seg_arr):
+    def __init__(self, x_in, ws, M, D, segs, seg_arr, qpre):
         self.x_in, self.ws, self.M, self.D, self.segs, self.seg_arr = x_in, ws, M, D, segs, seg_arr
+        self.qpre = qpre   # the forward stored q pre-scaled (option attn_softmax = 2 at forward time): vj_blocks_bwd flags bits 2-3
 
 
 def _blocks_of(views):
@@ -102,7 +103,8 @@ def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None, gemm_flags=0)
     st = torch.cuda.current_stream().cuda_stream if stream is None else stream
     check(lib.vj_blocks_fwd(arr, n, x.data_ptr(), out.data_ptr(), M, D, views.heads, sa, len(segs), ln_eps, int(save),
                             gemm_flags, ws.data_ptr(), ws.numel(), st), "vj_blocks_fwd")
-    return out, (TrunkCtx(x, ws, M, D, segs, sa) if save else None)
+    qpre = get_option("attn_softmax") == 2 and D % 4 == 0   # what vj_blocks_fwd just did (chain.hip: (3 * D) % 12 == 0)
+    return out, (TrunkCtx(x, ws, M, D, segs, sa, qpre) if save else None)
 
 
 def blocks_backward(dout, ctx, views, alpha, side_stream=None, on_layer_done=None, beta_acc=0.0, tag="bwd_tmp",
@@ -132,7 +134,8 @@ def blocks_backward(dout, ctx, views, alpha, side_stream=None, on_layer_done=Non
         dout.record_stream(torch.cuda.ExternalStream(side_stream, device=dout.device))
     check(lib.vj_blocks_bwd(arr, n, ctx.x_in.data_ptr(), dout.data_ptr(), dx.data_ptr(), M, D, views.heads, ctx.seg_arr,
                             len(ctx.segs), alpha, beta_acc, ctx.ws.data_ptr(), ctx.ws.numel(), tmp.data_ptr(),
-                            tmp.numel(), 2 if last_fc2_bias_done else 0, torch.cuda.current_stream().cuda_stream, side_stream, cb,
+                            tmp.numel(), (2 if last_fc2_bias_done else 0) | 8 | (4 if ctx.qpre else 0),
+                            torch.cuda.current_stream().cuda_stream, side_stream, cb,
                             None), "vj_blocks_bwd")
     if errs:
         raise errs[0]
