@@ -86,7 +86,8 @@ def build(wl, device, world_size):
         start_lr=HP["start_lr"], ref_lr=HP["lr"], final_lr=HP["final_lr"], iterations_per_epoch=HP["ipe"],
         warmup=HP["warmup"], num_epochs=HP["epochs"], ipe_scale=HP["ipe_scale"], mixed_precision=True,
         betas=HP["betas"], eps=HP["eps"], loss_exp=HP["loss_exp"], reg_coeff=HP["reg_coeff"], clip_grad=10.0,
-        world_size=world_size, device=device, micro_batch=wl.get("micro_batch"))
+        world_size=world_size, device=device, micro_batch=wl.get("micro_batch"),
+        overlap_update=os.environ.get("VJ_OVERLAP_UPDATE", "1") != "0")   # as app/vjepa/train.py runs it (optimization.overlap_update)
     return trainer, sched, wd_sched
 
 

@@ -351,10 +351,17 @@ int vj_comm_destroy(vj_comm_t comm);
  * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
  * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_tn",
  * "wgrad_group", "wgrad_slow_issue", "attn_dkdv_kt", "gemm_dbg", "attn_softmax", "bias_fuse", "gelu_poly", "gemm_sched", "attn_psum",
- * "attn_merge", "ln_bwd_prefetch", "gemm_raster" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * "attn_merge", "ln_bwd_prefetch", "gemm_raster", "ws_guard" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
  * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
 int vj_set_option(const char* name, int value);
 int vj_get_option(const char* name, int* value);
+
+/* Diagnostics (tests only).  With option "ws_guard" = 1 every member of the two chain workspaces (saved activations, backward
+ * temporaries, column partials, split-K partials) is followed by a 256-byte gap that vj_blocks_fwd / vj_blocks_bwd fill with a byte
+ * pattern before their first kernel; vj_ws_guard_check synchronises the device and reports how many distinct gaps were poisoned
+ * since the last call and how many of them no longer hold the pattern (a write past the end of a workspace member).  No reference
+ * counterpart. */
+int vj_ws_guard_check(int64_t* n_checked, int64_t* n_bad);
 
 /* ---- hardware probes (tests / profiles only) ---------------------------------------------------------------- */
 int vj_probe_tr16(uint32_t* out256, int addr_scale, vj_stream_t stream);

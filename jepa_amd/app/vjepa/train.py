@@ -67,6 +67,7 @@ _SCHEMA = (
     ('lr', 'optimization', 'lr', _REQUIRED, None), ('final_lr', 'optimization', 'final_lr', _REQUIRED, None),
     ('ema', 'optimization', 'ema', _REQUIRED, None), ('betas', 'optimization', 'betas', (0.9, 0.999), None),
     ('eps', 'optimization', 'eps', 1.e-8, None), ('micro_batch', 'optimization', 'micro_batch', None, None),
+    ('overlap_update', 'optimization', 'overlap_update', True, None),
     ('folder', 'logging', 'folder', _REQUIRED, None), ('tag', 'logging', 'write_tag', _REQUIRED, None),
 )
 
@@ -160,7 +161,7 @@ def main(args, resume_preempt=False):
         start_lr=cfg.start_lr, ref_lr=cfg.lr, final_lr=cfg.final_lr, iterations_per_epoch=ipe, warmup=warmup,
         num_epochs=num_epochs, ipe_scale=cfg.ipe_scale, mixed_precision=mixed_precision, betas=cfg.betas, eps=cfg.eps,
         loss_exp=cfg.loss_exp, reg_coeff=cfg.reg_coeff, clip_grad=clip_grad, world_size=world_size, device=device,
-        micro_batch=cfg.micro_batch)
+        micro_batch=cfg.micro_batch, overlap_update=bool(cfg.overlap_update))
     trainer = optimizer
     dp.broadcast_parameters(trainer.arena, trainer.tarena)   # DDP's one-time parameter sync (train.py:295-297)
     if world_size > 1:
@@ -185,6 +186,7 @@ def main(args, resume_preempt=False):
     def save_checkpoint(epoch, path):
         if rank != 0:
             return
+        trainer.sync_update()   # optimization.overlap_update: the last step's fused update may still be in flight on its own stream
         save_dict = {
             'encoder': _with_module_prefix(encoder.state_dict()),
             'predictor': _with_module_prefix(predictor.state_dict()),

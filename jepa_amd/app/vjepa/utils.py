@@ -97,7 +97,7 @@ class _NoScaler:
 def init_opt(encoder, predictor, iterations_per_epoch, start_lr, ref_lr, warmup, num_epochs, wd=1e-6,
              final_wd=1e-6, final_lr=0.0, mixed_precision=False, ipe_scale=1.25, betas=(0.9, 0.999), eps=1e-8,
              zero_init_bias_wd=True, target_encoder=None, loss_exp=1.0, reg_coeff=0.0, clip_grad=None,
-             world_size=1, device=None, micro_batch=None):
+             world_size=1, device=None, micro_batch=None, overlap_update=False):
     """Same schedules and parameter grouping as the reference; the returned optimizer is the fused Trainer.
     Extra keyword arguments (target_encoder, loss_exp, reg_coeff, clip_grad, world_size) configure the step; gradient
     non-finite checks (GradScaler's skip semantics) are always on and device-side."""
@@ -112,7 +112,8 @@ def init_opt(encoder, predictor, iterations_per_epoch, start_lr, ref_lr, warmup,
             p.requires_grad = False
         logger.info('init_opt: no target_encoder= given; the EMA target is optimizer.target_encoder (deep copy of encoder)')
     optimizer = Trainer(encoder, predictor, target_encoder, loss_exp=loss_exp, reg_coeff=reg_coeff, betas=betas,
-                        eps=eps, clip_grad=clip_grad, world_size=world_size, device=device, micro_batch=micro_batch)
+                        eps=eps, clip_grad=clip_grad, world_size=world_size, device=device, micro_batch=micro_batch,
+                        overlap_update=overlap_update)
     scheduler = WarmupCosineSchedule(optimizer, warmup_steps=int(warmup * iterations_per_epoch), start_lr=start_lr,
                                      ref_lr=ref_lr, final_lr=final_lr,
                                      T_max=int(ipe_scale * num_epochs * iterations_per_epoch))

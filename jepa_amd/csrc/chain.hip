@@ -20,6 +20,7 @@
 #include <vector>
 #include <string>
 #include <cstdlib>
+#include <algorithm>
 
 #define CH(call)              \
   do {                        \
@@ -37,6 +38,60 @@
 
 static inline int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
 static inline int64_t pad64i(int64_t m) { return (m + 63) / 64 * 64; }
+
+// ---------------------------------------------------------------------------------------------------- guard bands
+// Option ws_guard (diagnostics, tests/test_round5_gpu.py): every member of the two workspace layouts is followed by a 256-byte
+// gap.  A chain call fills the gaps of the workspace it was given with a byte pattern (in stream order, before its first
+// kernel) and remembers where they are; vj_ws_guard_check() synchronises the device and counts the gaps whose pattern
+// changed -- a kernel that writes past the end of a saved activation, a column-partial or a split-K buffer lands in one.
+#define GUARD_BYTES 256
+#define GUARD_PATTERN 0xA5
+static inline int64_t guard_gap() { return vj_opt(VJ_OPT_WS_GUARD) ? GUARD_BYTES : 0; }
+namespace {
+std::mutex g_guard_mu;
+std::vector<char*> g_guards;   // device addresses of the gaps poisoned so far (deduplicated at check time)
+int poison_gap(char* p, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(p, GUARD_PATTERN, GUARD_BYTES, st);
+  if (e != hipSuccess) {
+    vj_set_error("ws_guard: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guards.push_back(p);
+  return 0;
+}
+}  // namespace
+
+// -> number of damaged gaps (>= 0) in *n_bad, number of distinct gaps inspected in *n_checked; forgets the recorded gaps
+extern "C" int vj_ws_guard_check(int64_t* n_checked, int64_t* n_bad) {
+  VJ_CHECK_ARG(n_checked != nullptr && n_bad != nullptr, "vj_ws_guard_check: null output");
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    vj_set_error("vj_ws_guard_check: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  std::sort(g_guards.begin(), g_guards.end());
+  g_guards.erase(std::unique(g_guards.begin(), g_guards.end()), g_guards.end());
+  *n_checked = (int64_t)g_guards.size();
+  *n_bad = 0;
+  unsigned char host[GUARD_BYTES];
+  for (char* p : g_guards) {
+    e = hipMemcpy(host, p, GUARD_BYTES, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      vj_set_error("vj_ws_guard_check: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    bool bad = false;
+    for (int i = 0; i < GUARD_BYTES; i++) bad |= host[i] != GUARD_PATTERN;
+    if (bad) {
+      if (*n_bad == 0) vj_set_error("vj_ws_guard_check: first damaged gap at device address %p", (void*)p);
+      *n_bad += 1;
+    }
+  }
+  g_guards.clear();
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------------------- event pool
 // Ordering events (no timing) reused round-robin: hipStreamWaitEvent captures the record that precedes it at call time,
@@ -157,13 +212,21 @@ static int gemm(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
 
 struct FwdLayout {
   int64_t x, y1, qkv, o, x1, y2, u, g, mean1, rstd1, mean2, rstd2, lse, total;
+  int64_t gap[16];   // option ws_guard: offsets of the 256-byte gaps behind the members
+  int n_gap;
 };
 static FwdLayout fwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
   FwdLayout L;
+  L.n_gap = 0;
+  const int64_t gg = guard_gap();
   int64_t off = 0;
   auto take = [&](int64_t bytes) {
     int64_t o = off;
     off += al256(bytes);
+    if (gg) {
+      L.gap[L.n_gap++] = off;
+      off += gg;
+    }
     return o;
   };
   L.x = take(M * D * 2);
@@ -185,7 +248,7 @@ static FwdLayout fwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
 
 extern "C" int64_t vj_blocks_fwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads, int64_t n_blocks, int save) {
   const FwdLayout L = fwd_layout(M, D, Dh, heads);
-  return save ? L.total * n_blocks : L.total + al256(M * D * 2);
+  return save ? L.total * n_blocks : L.total + al256(M * D * 2) + guard_gap();
 }
 
 static int check_blocks(const vj_block_t* blocks, int64_t n_blocks, int64_t D, const char* who) {
@@ -231,6 +294,11 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
                (long)vj_blocks_fwd_ws_bytes(M, D, Dh, heads, n_blocks, save));
   VJ_CHECK_ARG(((uintptr_t)ws & 255) == 0, "vj_blocks_fwd: workspace must be 256-byte aligned");
   const FwdLayout L = fwd_layout(M, D, Dh, heads);
+  if (L.n_gap) {   // option ws_guard
+    for (int64_t li = 0; li < (save ? n_blocks : 1); li++)
+      for (int k = 0; k < L.n_gap; k++) CH(poison_gap((char*)ws + li * L.total + L.gap[k], stream));
+    if (!save) CH(poison_gap((char*)ws + L.total + al256(M * D * 2), stream));
+  }
   const bool merge_segs = n_segs > 1 && n_segs <= 4 && vj_opt(VJ_OPT_ATTN_MERGE) != 0;
   const bool qpre = vj_opt(VJ_OPT_ATTN_SOFTMAX) == 2 && (3 * D) % 12 == 0;
   const float ascale = qpre ? -scale : scale;   // negative: "q is pre-scaled" (vj_attn_fwd_segs)
@@ -294,16 +362,24 @@ struct BwdLayout {
   int64_t du[2], dx1[2], dqkv[2], dx[3], dy2, dob, dy1, delta, ln_ws, ln_ws2, colp_fc1, colp_q, colp_kv, dyT[2], xT[2], tcs_ws[2],
       wg_ws[2], total;
   int64_t ln_ws_bytes, tcs_ws_bytes, delta_bytes, colp_fc1_rows, colp_attn_rows;
+  int64_t gap[32];   // option ws_guard
+  int n_gap;
 };
 int vj_layernorm_bwd_partials(const void* dy_bf16, const void* x_bf16, const float* gamma, const float* mean, const float* rstd,
                               const void* dres_bf16, void* dx_bf16, bool cs, int64_t rows, int64_t D, void* ws,
                               int64_t ws_bytes, int64_t* nb_out, hipStream_t stream);   // norm_loss.hip
 static BwdLayout bwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
   BwdLayout L;
+  L.n_gap = 0;
+  const int64_t gg = guard_gap();
   int64_t off = 0;
   auto take = [&](int64_t bytes) {
     int64_t o = off;
     off += al256(bytes);
+    if (gg) {
+      L.gap[L.n_gap++] = off;
+      off += gg;
+    }
     return o;
   };
   const int64_t Mp = pad64i(M), nmax = 3 * D > Dh ? 3 * D : Dh;
@@ -434,6 +510,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
   }
   const char* sv = (const char*)save_ws;
   char* tmp = (char*)tmp_ws;
+  for (int k = 0; k < L.n_gap; k++) CH(poison_gap(tmp + L.gap[k], stream));   // option ws_guard
   SideCtx sc{stream, side ? side : stream, tmp, &L, M, alpha, beta_acc, ((flags & 1) || vj_opt(VJ_OPT_WGRAD_TN)) ? 1 : 0};
   constexpr int MAX_BLOCKS = 256;
   VJ_CHECK_ARG(n_blocks <= MAX_BLOCKS, "vj_blocks_bwd: more than %d blocks", MAX_BLOCKS);

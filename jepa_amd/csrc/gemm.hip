@@ -264,13 +264,20 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
 int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);  // gemm8.hip
 int vj_gemm_launch_4w(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);      // gemm4w.hip
 int vj_gemm_launch_8phase_persist(const GemmArgs& a, int epilogue, hipStream_t stream);                        // gemm8p.hip (-100: n/a)
+int vj_gemm_launch_4wp(const GemmArgs& a, int epilogue, hipStream_t stream);                                   // gemm4w.hip (-100: n/a)
 
 template <int EPI>
-static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {   // (flags: by value, edited below)
   const bool reg_staged = (flags & 1) != 0;
   int cfg = (flags >> 4) & 3;
   int pipe = (flags >> 6) & 3;
   const bool is_wgrad = (EPI == EPI_F32 && ws != nullptr);
+  // bit 9 (round 5): the PERSISTENT form of the 4-wave kernel (two workgroups per CU walking tile lists); bit-identical outputs
+  if ((flags & 0x200) && !is_wgrad && !reg_staged) {
+    const int rc = vj_gemm_launch_4wp(a, EPI, stream);
+    if (rc != -100) return rc;
+    flags &= ~0x200;
+  }
   // bit 8: the 4-wave 256x128 kernel with two workgroups per CU (gemm4w.hip)
   if ((flags & 0x100) && a.K % 64 == 0 && !reg_staged) return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
   if (pipe == 0 && cfg == 0) {
@@ -290,6 +297,13 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     // 2: only where a 256-wide tile wastes a third of its columns (N = 384: the predictor's proj / fc2 / dgrad outputs)
     if (use_4w == 2 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 64 && a.N % 256 == 128 && a.N < 512)
       return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
+    // 3 (round 5): the persistent 4-wave kernel wherever the persistent 8-phase kernel would run; 4: only for K <= 512 (the predictor's
+    // short-K shapes, where the per-tile fixed cost is ~45 % of a tile); 5: only for N <= 1152 and K <= 1024 (+ the N = K = 1024 projections)
+    if (use_4w >= 3 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 180 &&
+        (use_4w == 3 || (use_4w == 4 && a.K <= 512) || (use_4w == 5 && a.K <= 1024 && a.N <= 1152))) {
+      const int rc = vj_gemm_launch_4wp(a, EPI, stream);
+      if (rc != -100) return rc;
+    }
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
     if (!is_wgrad && a.K % 64 == 0 && t256 >= 90) pipe = 3;
     if (is_wgrad && a.K % 64 == 0 && t256 >= 40) pipe = 3;   // qkv/fc1/fc2 wgrads: 8-phase + split-K (0.97-1.08 vs 0.78-0.96 PF)
@@ -386,7 +400,7 @@ extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const vo
   VJ_CHECK_ARG(fused != nullptr, "vj_gemm_bf16_nt_dgelu_colsum: null `fused`");
   *fused = 0;
   const int64_t t256 = cdiv64(M, 256) * cdiv64(N, 256);
-  if (colpart != nullptr && flags == 0 && M > 0 && N > 0 && K > 0 && K % 64 == 0 && t256 >= 90 && vj_opt(VJ_OPT_GEMM_4W) == 0 &&
+  if (colpart != nullptr && (flags & ~0x200) == 0 && M > 0 && N > 0 && K > 0 && K % 64 == 0 && t256 >= 90 && (vj_opt(VJ_OPT_GEMM_4W) == 0 || vj_opt(VJ_OPT_GEMM_4W) >= 3) &&
       vj_opt(VJ_OPT_GEMM_PERSIST) != 0 && vj_opt(VJ_OPT_GEMM_DBG) == 0 && aux_in != nullptr && lda % 8 == 0 && ldb % 8 == 0 &&
       lda >= K && ldb >= K && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ldc % 4 == 0 && ldc >= N &&
       ldaux % 4 == 0 && N % 4 == 0 && (uintptr_t)C % 8 == 0) {

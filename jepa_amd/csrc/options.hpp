@@ -13,7 +13,9 @@ enum VjOpt {
   VJ_OPT_GEMM_FWD_FLAGS = 0,   // vj_gemm_bf16_nt flags for the chains' forward GEMMs (0 = automatic selection)
   VJ_OPT_GEMM_DGRAD_FLAGS,     // ... for the chains' dgrad GEMMs
   VJ_OPT_GEMM_4W,              // 1: every forward / dgrad GEMM on the 4-wave 256x128 kernel; 2: only N = 384 outputs (a 256-wide
-                               // tile wastes a third there; -0.10 ms/step, 6 of 6 rounds: profiles/r03_abab_n384_policy.md)
+                               // tile wastes a third there; -0.10 ms/step, 6 of 6 rounds: profiles/r03_abab_n384_policy.md);
+                               // 3 / 4 / 5 (round 5): the PERSISTENT two-workgroups-per-CU form (gemm_nt_4wp_kernel) for every shape the
+                               // persistent 8-phase kernel takes / only K <= 512 / only K <= 1024 and N <= 1152
   VJ_OPT_GEMM_PERSIST,         // 1 (default): persistent 8-phase kernel (gemm8p.hip) where it applies (single-round shapes
                                // included), trimmed grid; 2: one
                                // workgroup per CU; 0: always one tile per workgroup (gemm8.hip)
@@ -52,6 +54,8 @@ enum VjOpt {
                                // are still 8 rows x 4 columns, but its band walks down the rows of one column group, so the B panels stay in its L2 and
                                // every A panel streams through once per column group: fabric reads of the encoder shapes -14 ... -38 %, step -0.6 ... -0.8 ms
                                // (profiles/r04_gemm_raster.md).  0 = the order of rounds 2-4 (groups of 8 row tiles).  Bit-identical results
+  VJ_OPT_WS_GUARD,             // diagnostics: 1 = 256-byte guard gaps behind every member of the chain workspaces, poisoned by the chain calls and
+                               // inspected by vj_ws_guard_check (tests/test_round5_gpu.py).  Changes the workspace sizes: set it before the first step
   VJ_OPT_COUNT
 };
 

@@ -89,8 +89,14 @@ def _blocks_of(views):
     return arr
 
 
-def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None, gemm_flags=0):
-    """x [M, D] bf16 -> (x_out [M, D] bf16, TrunkCtx or None).  `views`: EncoderW / PredictorW (`.blocks`, `.heads`)."""
+def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None, gemm_flags=0, gates=None):
+    """x [M, D] bf16 -> (x_out [M, D] bf16, TrunkCtx or None).  `views`: EncoderW / PredictorW (`.blocks`, `.heads`).
+
+    gates: optional [(first_block, torch.cuda.Event)] -- the weights of blocks >= first_block may only be read after the event
+    (the fused AdamW / EMA update of the previous step, issued range by range on its own stream: engine/step.py).  The trunk is
+    then enqueued as one vj_blocks_fwd call per gated range, each behind a wait on its event; the ranges share the workspace
+    exactly as one call lays it out (a range's output IS the next block's saved input slot), so the backward and the results
+    are the same as for a single call."""
     lib = load_library()
     M, D = x.shape
     arr = _blocks_of(views)
@@ -101,9 +107,39 @@ def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None, gemm_flags=0)
     out = torch.empty_like(x)
     sa = seg_array(segs)
     st = torch.cuda.current_stream().cuda_stream if stream is None else stream
-    check(lib.vj_blocks_fwd(arr, n, x.data_ptr(), out.data_ptr(), M, D, views.heads, sa, len(segs), ln_eps, int(save),
-                            gemm_flags, ws.data_ptr(), ws.numel(), st), "vj_blocks_fwd")
-    qpre = get_option("attn_softmax") == 2 and D % 4 == 0   # what vj_blocks_fwd just did (chain.hip: (3 * D) % 12 == 0)
+    qpre = get_option("attn_softmax") == 2 and D % 4 == 0   # what vj_blocks_fwd is about to do (chain.hip: (3 * D) % 12 == 0)
+    cuts = sorted({b for b, _ in gates if 0 < b < n}) if gates else []
+    if not cuts:
+        check(lib.vj_blocks_fwd(arr, n, x.data_ptr(), out.data_ptr(), M, D, views.heads, sa, len(segs), ln_eps, int(save),
+                                gemm_flags, ws.data_ptr(), ws.numel(), st), "vj_blocks_fwd")
+        return out, (TrunkCtx(x, ws, M, D, segs, sa, qpre) if save else None)
+    if stream is not None:
+        raise ValueError("blocks_forward: gated ranges are enqueued on the current torch stream")
+    ev = {b: e for b, e in gates}
+    per_block = lib.vj_blocks_fwd_ws_bytes(M, D, Dh, views.heads, 1, 1)   # one block's saved set; its first member is the block input
+    sel_from = (gemm_flags >> 16) & 0xff
+    cur = torch.cuda.current_stream()
+    cur_in, keep = x.data_ptr(), []
+    for b0, b1 in zip([0] + cuts, cuts + [n]):
+        if b0 > 0:
+            cur.wait_event(ev[b0])
+        last = b1 == n
+        if save:
+            ws_ptr, ws_left = ws.data_ptr() + b0 * per_block, ws.numel() - b0 * per_block
+            out_ptr = out.data_ptr() if last else ws.data_ptr() + b1 * per_block
+        else:
+            ws_ptr, ws_left = ws.data_ptr(), ws.numel()
+            if last:
+                out_ptr = out.data_ptr()
+            else:
+                keep.append(torch.empty_like(x))
+                out_ptr = keep[-1].data_ptr()
+        rel = max(0, sel_from - b0)                       # "first block the kernel selection applies to", relative to this call
+        flags = 0 if (gemm_flags >> 16 and rel >= b1 - b0) else (gemm_flags & 0xffff) | (rel << 16)
+        sub = ctypes.cast(ctypes.byref(arr, b0 * ctypes.sizeof(VjBlock)), ctypes.POINTER(VjBlock))
+        check(lib.vj_blocks_fwd(sub, b1 - b0, cur_in, out_ptr, M, D, views.heads, sa, len(segs), ln_eps, int(save), flags,
+                                ws_ptr, ws_left, st), "vj_blocks_fwd")
+        cur_in = out_ptr
     return out, (TrunkCtx(x, ws, M, D, segs, sa, qpre) if save else None)
 
 

@@ -10,7 +10,7 @@ layer chain, so `loss.backward()` + any torch optimizer keep working on these mo
 """
 import torch
 
-from .weights import ARENA_GENERATION, ParamArena
+from .weights import ARENA_GENERATION, ParamArena, wait_pending_update
 
 
 def require_gpu(t, what):
@@ -30,6 +30,7 @@ class HipModule:
         return [n for n, m in self.named_modules() if isinstance(m, torch.nn.Linear)]
 
     def _hip_arena(self, train):
+        wait_pending_update()   # a Trainer's deferred update (overlap_update) must have run before these weights are read
         shared = self.__dict__.get("_hip_shared")
         if shared is not None:
             return shared

@@ -224,11 +224,23 @@ def block_backward(dx2, saved, bw: BlockW, segs: List[Seg], heads: int, alpha: f
 
 
 # =============================================================================================== encoder
+def _wait_gates(gates, chained):
+    """gates [(first_block, event)]: the weights of blocks >= first_block are final after the event (the previous step's
+    range-by-range update, engine/step.py).  The entry gate (block 0: embedding + first range) is waited for here; with the
+    C chain the later ones are waited for between the ranges of the trunk (chain.blocks_forward), otherwise all of them now."""
+    if not gates:
+        return
+    cur = torch.cuda.current_stream()
+    for b, ev in gates:
+        if b == 0 or not chained:
+            cur.wait_event(ev)
+
+
 def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], save: bool, final_norm=True, ws_tag=None,
-                    gemm_flags=0):
+                    gemm_flags=0, gates=None):
     """clips fp32 [B,3,T,H,W]; masks: None (all N tokens) or a list of int64 [B,K_i] index tensors.
     Returns (out [sum_i B*K_i, D] bf16, segs, saved).  With final_norm=False the last residual stream is returned
-    (the target path fuses the final norm into vj_target_rows)."""
+    (the target path fuses the final norm into vj_target_rows).  gates: see _wait_gates."""
     B = clips.shape[0]
     D = ew.patch.w.shape[0]
     kdim = ew.patch.w.shape[1]
@@ -244,11 +256,13 @@ def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], sa
         tok = torch.empty((r, kdim), dtype=torch.bfloat16, device=clips.device)
         for sg, m in zip(segs, masks):
             ops.tubelet_pack(clips, ew.tubelet, ew.patch_size, idx=m, out=_rows(tok, sg))
+    chained = ws_tag is not None and USE_C_CHAIN
+    _wait_gates(gates, chained)
     x = ops.gemm_nt(tok, ew.patch.w, bias=ew.patch.b, flags=(gemm_flags & 0xffff if not gemm_flags >> 16 else 0) or None)
     for i, sg in enumerate(segs):
         ops.add_pos(_rows(x, sg), ew.pos, sg.B, sg.S, idx=None if masks is None else masks[i])
-    if ws_tag is not None and USE_C_CHAIN:    # ws_tag: the caller owns one workspace per trunk (engine/chain.py)
-        x, saved_blocks = chain.blocks_forward(x, ew, segs, save, ws_tag, LN_EPS, gemm_flags=gemm_flags)
+    if chained:    # ws_tag: the caller owns one workspace per trunk (engine/chain.py)
+        x, saved_blocks = chain.blocks_forward(x, ew, segs, save, ws_tag, LN_EPS, gemm_flags=gemm_flags, gates=gates)
     else:
         saved_blocks = []
         for bw in ew.blocks:
@@ -293,11 +307,12 @@ def encoder_backward(dout, saved, ew: EncoderW, segs, alpha: float, on_layer_don
 
 # =============================================================================================== predictor
 def predictor_forward(pw: PredictorW, z, enc_segs: List[Seg], masks_enc, masks_pred, save: bool, ws_tag=None,
-                      gemm_flags=0):
+                      gemm_flags=0, gates=None):
     """z [sum_i B*Ke_i, D] bf16 (context-encoder output rows, per-mask segments enc_segs).
-    Returns (zhat [sum_i B*Kp_i, D] bf16, tgt_segs, saved)."""
+    Returns (zhat [sum_i B*Kp_i, D] bf16, tgt_segs, saved).  gates: [(0, event)] -- the predictor's weights are one range."""
     Dp = pw.embed.w.shape[0]
     dev = z.device
+    _wait_gates(gates, False)
     e = ops.gemm_nt(z, pw.embed.w, bias=pw.embed.b)
     n_tok = len(pw.mask_tokens)
     segs, tsegs, r, rt = [], [], 0, 0

@@ -23,6 +23,7 @@ import weakref
 
 from . import chain, dp, optstate
 from .layers import encoder_backward, encoder_forward, predictor_backward, predictor_forward, side_stream
+from . import weights as _weights
 from .weights import ParamArena, bump_generation, encoder_views, is_no_decay, predictor_views
 
 
@@ -115,7 +116,7 @@ def _strip(name):
 class Trainer:
     def __init__(self, encoder, predictor, target_encoder, loss_exp=1.0, reg_coeff=0.0, betas=(0.9, 0.999),
                  eps=1e-8, clip_grad=None, device=None, world_size=1, overlap_comm=True, check_finite=True,
-                 micro_batch=None):
+                 micro_batch=None, overlap_update=False):
         self.encoder, self.predictor, self.target_encoder = encoder, predictor, target_encoder
         self.vit, self.pred, self.tvit = encoder.backbone, predictor.backbone, target_encoder.backbone
         self.device = torch.device(device) if device is not None else next(encoder.parameters()).device
@@ -185,6 +186,15 @@ class Trainer:
         self._step_dev = torch.zeros(1, dtype=torch.float32, device=dev)   # Adam step count t (advanced on the device)
         self._stat = torch.zeros(8, dtype=torch.float32, device=dev)   # [loss_jepa, loss_reg, -, -, sq_enc, bad, sq_pred, bad]
         self.reducer = dp.GradReducer(self.arena, self.vit, self.pred, world_size, overlap=overlap_comm)
+        # overlap_update: train_step returns with the fused AdamW / EMA update only ENQUEUED, on its own stream, range by range in
+        # the order the next step's forward consumes the weights; the next train_step waits per range instead of for the whole
+        # update (the update is 12.7 GB of HBM traffic that used to run with the chip otherwise empty).  Same kernels over the
+        # same elements: results are bit-identical.  Off by default because anything that reads parameters with plain torch
+        # operators right after train_step must then call sync_update() first (everything inside this package does).
+        self.overlap_update = bool(overlap_update)
+        self._upd_stream = None     # created on first use (the flag may be flipped between steps: tools/abab.py)
+        self._gates = None          # {'enc': [(first_block, event)], 'pred': [(0, event)], 'done': event} of the pending update
+        self._plan = self._update_plan()
 
     # ------------------------------------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -192,7 +202,7 @@ class Trainer:
         """h_i = apply_masks(F.layer_norm(target_encoder(clips)), masks_pred)  (train.py:419-429), fp32."""
         B = clips.shape[0]
         x, _, _ = encoder_forward(self.tw, clips, None, save=False, final_norm=False, ws_tag=self._ws + "tgt",
-                                  gemm_flags=_TGT_GEMM_FLAGS)
+                                  gemm_flags=_TGT_GEMM_FLAGS, gates=self._gate("enc"))
         N = self.tvit.num_patches
         return [ops.target_rows(x, self.tw.norm.g, self.tw.norm.b, mp, B, N, 1e-6, 1e-5) for mp in masks_pred]
 
@@ -238,8 +248,9 @@ class Trainer:
                     h = self.forward_target(cl, mp)
             else:
                 h = self.forward_target(cl, mp)
-            z, segs, saved_e = encoder_forward(self.ew, cl, me, save=True, ws_tag=self._ws + "enc_save")
-            zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, me, mp, save=True, ws_tag=self._ws + "pred_save")
+            z, segs, saved_e = encoder_forward(self.ew, cl, me, save=True, ws_tag=self._ws + "enc_save", gates=self._gate("enc"))
+            zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, me, mp, save=True, ws_tag=self._ws + "pred_save",
+                                                     gates=self._gate("pred"))
             mark('context+predictor forward (main stream)')
             if fwd_overlap:
                 side.join()
@@ -261,7 +272,11 @@ class Trainer:
                                  t.S, D, n_masks, coef)
             mark('target forward joined + loss')
             # ---- backward (predictor first, then encoder layers L-1..0); on the last micro-batch the gradient
-            #      buckets go out as layers finish
+            #      buckets go out as layers finish.  A pending update (overlap_update) must be complete first: the backward
+            #      overwrites the gradients it reads and uses the W^T shadows it refreshes last.
+            if self._gates is not None:
+                torch.cuda.current_stream().wait_event(self._gates["done"])
+                self._gates = None
             if last:
                 self.reducer.begin(side.stream if side.enabled else None)
             lhook = hook if last else None
@@ -299,6 +314,52 @@ class Trainer:
     def opt_step(self, v):
         self._step_dev.fill_(float(v))
 
+    def _gate(self, which):
+        return None if self._gates is None else self._gates[which]
+
+    def sync_update(self):
+        """Make the current stream wait for a pending update (overlap_update): call before reading parameters, moments or
+        the EMA target with plain torch operators right after train_step.  No-op otherwise."""
+        if self._gates is not None:
+            torch.cuda.current_stream().wait_event(self._gates["done"])
+            self._gates = None
+
+    def _update_plan(self):
+        """[(which, first_block, [(group, lo, hi)])]: the arena ranges of the fused update in the order the forward reads
+        them -- encoder blocks in a few ranges of growing size (the first holds the patch embedding, the last the final
+        norm; each is one slice of the decayed and one of the no-decay group, which the EMA target arena mirrors), then the
+        predictor.  Falls back to the four whole groups if the arena is not laid out in forward order."""
+        A = self.arena
+        depth = len(self.ew.blocks)
+        cuts = sorted({min(depth, max(1, math.ceil(depth * f))) for f in (1.0 / 12, 0.25, 0.5, 1.0)})
+        firsts = [0] + cuts[:-1]
+
+        def stage_of(name):   # enc.<...>: which range of the plan the tensor belongs to
+            parts = name.split(".")
+            if parts[1] == "blocks":
+                b = int(parts[2])
+                return max(i for i, f in enumerate(firsts) if f <= b)
+            return 0 if parts[1] == "patch_embed" else len(firsts) - 1
+        plan, ok = [], True
+        per_stage = [[] for _ in firsts]
+        for gi in (0, 1):
+            lo, hi = A.group_ranges[gi]
+            slots = sorted((s for n, s in A.slots.items() if n.startswith("enc.") and lo <= s.off < hi), key=lambda s: s.off)
+            stages = [stage_of(s.name) for s in slots]
+            ok = ok and stages == sorted(stages) and set(stages) == set(range(len(firsts)))
+            if not ok:
+                break
+            starts = [min(s.off for s, st in zip(slots, stages) if st == k) for k in range(len(firsts))]
+            starts[0] = lo
+            for k in range(len(firsts)):
+                per_stage[k].append((gi, starts[k], starts[k + 1] if k + 1 < len(firsts) else hi))
+        if ok:
+            plan = [("enc", firsts[k], per_stage[k]) for k in range(len(firsts))]
+        else:
+            plan = [("enc", 0, [(gi,) + tuple(A.group_ranges[gi]) for gi in (0, 1)])]
+        plan.append(("pred", 0, [(gi,) + tuple(A.group_ranges[gi]) for gi in (2, 3)]))
+        return plan
+
     def _enc_pred_ranges(self):
         A = self.arena
         (e0, _), (_, e1) = A.group_ranges[0], A.group_ranges[1]
@@ -310,6 +371,7 @@ class Trainer:
         on the device: two sum-of-squares passes over the gradient arena feed the fused update kernel."""
         A = self.arena
         inv_world = 1.0 / self.world_size
+        self.sync_update()   # (an update still pending here can only come from a caller that mixes the two entry points)
         (e0, e1), (p0, p1) = self._enc_pred_ranges()
         ops.sqnorm(A.G[e0:e1], self._stat[4:6])
         ops.sqnorm(A.G[p0:p1], self._stat[6:8])
@@ -318,9 +380,10 @@ class Trainer:
         clip = float(self.clip_grad) if (clip_now and self.clip_grad is not None) else 0.0
         b1, b2 = self.betas
         T = self.tarena
-        for gi, (lo, hi) in enumerate(A.group_ranges):
+
+        def update(gi, lo, hi):
             if hi == lo:
-                continue
+                return
             is_enc = gi < 2
             decay = wd if gi in (0, 2) else 0.0
             tgt = T.P[lo - T.lo:hi - T.lo] if is_enc else None
@@ -328,7 +391,34 @@ class Trainer:
             ops.adamw_ema_guarded(A.P[lo:hi], A.G[lo:hi], A.M1[lo:hi], A.M2[lo:hi], A.Pb[lo:hi], tgt, tgtb, lr, decay, b1,
                                   b2, self.eps, inv_world, ema, gstat, 0 if is_enc else 1, clip, inv_world,
                                   self._step_dev)
-        A.refresh_transposed()
+
+        if self.overlap_update and side_stream(self.device).enabled:
+            # range by range on the update stream, in the order the next forward reads the weights; one event per range
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)          # gradients, norms and the step count are final
+            if self._upd_stream is None:
+                self._upd_stream = torch.cuda.Stream(device=self.device)
+            upd = self._upd_stream
+            upd.wait_event(ready)
+            gates = {"enc": [], "pred": []}
+            with torch.cuda.stream(upd):
+                for which, first_block, ranges in self._plan:
+                    for gi, lo, hi in ranges:
+                        update(gi, lo, hi)
+                    ev = torch.cuda.Event()
+                    ev.record(upd)
+                    gates[which].append((first_block, ev))
+                A.refresh_transposed()
+                done = torch.cuda.Event()
+                done.record(upd)
+            gates["done"] = done
+            self._gates = gates
+            _weights.PENDING_UPDATE[self.device.index] = done
+        else:
+            for gi, (lo, hi) in enumerate(A.group_ranges):
+                update(gi, lo, hi)
+            A.refresh_transposed()
         bump_generation()   # parameters changed behind torch's version counters: derived-weight caches must refresh
         for g in self.param_groups:
             g["lr"] = lr
@@ -343,6 +433,7 @@ class Trainer:
         Cached until the next train_step."""
         if self._arena_stats is not None:
             return self._arena_stats
+        self.sync_update()
         if self._gs_desc is None:
             order = [("enc", a, n, p) for a, n, p in self._enc_named if p.requires_grad]
             order += [("pred", a, n, p) for a, n, p in self._pred_named if p.requires_grad]
@@ -380,17 +471,20 @@ class Trainer:
     def state_dict(self):
         """torch.optim.AdamW-compatible optimizer state (reference checkpoint key 'opt', train.py:331-342): parameter ids
         count every member of the reference's four groups (frozen position tables included, stateless)."""
+        self.sync_update()
         return optstate.build_state_dict(self.param_groups, self._slot_of, self.arena.M1, self.arena.M2, self.opt_step,
                                          self.betas, self.eps)
 
     def load_state_dict(self, sd):
         """Accepts our own state_dict() and the 'opt' entry of a reference checkpoint (same grouping and ids)."""
+        self.sync_update()
         step = optstate.load_state_dict(self.param_groups, self._slot_of, self.arena.M1, self.arena.M2, sd)
         if step is not None:
             self.opt_step = step
 
     def sync_shadows(self):
         """Call after writing parameters from outside (load_state_dict): refresh bf16 / transposed shadows."""
+        self.sync_update()
         self.arena.refresh_bf16()
         self.arena.refresh_transposed()
         self.tarena.refresh_bf16()

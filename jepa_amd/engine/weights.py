@@ -28,6 +28,22 @@ def bump_generation():
     ARENA_GENERATION[0] += 1
 
 
+# Trainer(overlap_update=True) issues the fused AdamW / EMA update on its own stream and returns before it has run; the NEXT
+# train_step orders itself against it range by range.  Every OTHER reader of the parameters inside this package (module-level
+# forwards, logging, checkpoints) calls wait_pending_update() first: the current stream then waits for the last update.
+# Code outside the package that reads `param.data` with torch operators must call `trainer.sync_update()` itself.
+PENDING_UPDATE = {}   # device index -> torch.cuda.Event recorded after the last range (and the W^T refresh) of the update
+
+
+def wait_pending_update(device=None):
+    if not PENDING_UPDATE:
+        return
+    idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
+    ev = PENDING_UPDATE.get(idx)
+    if ev is not None:
+        torch.cuda.current_stream(idx).wait_event(ev)
+
+
 from .optstate import ALIGN, Slot as _Slot, is_no_decay, layout, pad64 as _pad  # noqa: F401  (pure, CPU-testable)
 
 

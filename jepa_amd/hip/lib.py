@@ -118,6 +118,7 @@ SIGNATURES = {
     "vj_probe_tr16": (I32, [P, I32, P]),
     "vj_probe_copy": (I32, [P, P, I64, P]),
     "vj_probe_lds_bw": (I32, [P, I32, I32, I32, P]),
+    "vj_ws_guard_check": (I32, [I64P, I64P]),
 }
 
 

@@ -25,7 +25,8 @@ def _no_grad_only(module, x, what):
 def _bf16_weights(module):
     """bf16 copies of the Linear weights of `module`, refreshed when a parameter's version counter moved or the fused
     Trainer rewrote parameters through its arenas (raw-pointer writes that torch's version counters do not see)."""
-    from ....engine.weights import ARENA_GENERATION
+    from ....engine.weights import ARENA_GENERATION, wait_pending_update
+    wait_pending_update()   # a Trainer's deferred update must have run before its parameters are read
     key = (ARENA_GENERATION[0],) + tuple((p.data_ptr(), p._version) for p in module.parameters())
     cache = module.__dict__.get("_hip_w")
     if cache is None or cache[0] != key:

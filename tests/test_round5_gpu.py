@@ -1,0 +1,274 @@
+"""Round-5 GPU tests.
+
+* the fused AdamW / EMA update issued range by range on its own stream (Trainer(overlap_update=True)) and the gated, range-wise
+  enqueue of the trunks that goes with it: bitwise the same weights, moments, EMA target and shadows as the single-stream update;
+* guard bands (one unexplained "Memory access fault" in round 4): every member of the chain workspaces
+  followed by a poisoned 256-byte gap (option ws_guard) + poisoned 4 KB bands around the workspaces themselves, over the
+  BASELINE model sizes and over tile orders of the persistent GEMM; single GEMMs with poisoned bands around every output for
+  ALL 512 values option gemm_raster admits.
+Every kernel is reached through the C ABI; tolerances (here: bitwise) are next to each assertion."""
+import ctypes
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.step_util import TINY, TINY_MASKS, VITH, VITL, VITL_MASKS, build_trainer, draw_batch, to_dev  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from jepa_amd.hip import ops as o
+    return o
+
+
+def _gens(masks=TINY_MASKS, m=TINY):
+    from oracle import vjepa_oracle as O
+    return O.make_mask_gens(masks, m["crop"], m["frames"], m["patch"], m["tubelet"])
+
+
+class _opt:
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        from jepa_amd.hip.lib import set_option
+        self.old = set_option(self.name, self.value)
+
+    def __exit__(self, *a):
+        from jepa_amd.hip.lib import set_option
+        set_option(self.name, self.old)
+
+
+# ------------------------------------------------------------------------------------------ deferred, range-wise update
+def _state(tr):
+    tr.sync_update()
+    torch.cuda.synchronize()
+    A, T = tr.arena, tr.tarena
+    out = dict(P=A.P.clone(), Pb=A.Pb.clone(), M1=A.M1.clone(), M2=A.M2.clone(), G=A.G.clone(), TP=T.P.clone(), TPb=T.Pb.clone())
+    for n, t in A.wT.items():
+        out["wT:" + n] = t.clone()
+    return out
+
+
+@pytest.mark.parametrize("micro", [None, 2])
+def test_overlapped_update_is_bit_identical(micro):
+    """ViT-Tiny (12 blocks -> four encoder ranges + the predictor), six steps with warm-up-style lr, weight decay, EMA < 1 and an
+    active clip: Trainer(overlap_update=True) -- update on its own stream, the next step's forwards gated range by range, the
+    trunks enqueued as one vj_blocks_fwd call per range -- against the plain Trainer.  Everything the step owns is compared
+    bitwise after every step: master weights, bf16 / transposed shadows, both Adam moments, gradients, EMA target."""
+    trs = [build_trainer(TINY, 2, perturb_small=True, clip_grad=0.05, micro_batch=micro, overlap_update=ov)[0] for ov in (False, True)]
+    plan = trs[1]._plan
+    assert [w for w, _, _ in plan] == ["enc"] * 4 + ["pred"] and [f for _, f, _ in plan][:4] == [0, 1, 3, 6], plan
+    # the ranges tile the four groups exactly
+    for gi in range(4):
+        lo, hi = trs[1].arena.group_ranges[gi]
+        segs = sorted((a, b) for _, _, rs in plan for g, a, b in rs if g == gi)
+        assert segs[0][0] == lo and segs[-1][1] == hi and all(x[1] == y[0] for x, y in zip(segs, segs[1:])), (gi, segs)
+    losses = [[], []]
+    for step in range(6):
+        gens = _gens()
+        for _ in range(step + 1):
+            clips, me, mp = draw_batch(gens, 4, TINY, 300 + step, 400 + step)
+        cd, med, mpd = to_dev(clips, me, mp)
+        for k, tr in enumerate(trs):
+            o = tr.train_step(cd, med, mpd, lr=1e-3 * (step + 1), wd=0.04, ema=0.99, clip_now=step >= 2)
+            losses[k].append(o)
+        a, b = _state(trs[0]), _state(trs[1])
+        for key in a:
+            assert torch.equal(a[key], b[key]), (step, key, int((a[key] != b[key]).sum()))
+    for oa, ob in zip(*losses):
+        assert oa.loss == ob.loss and oa.raw_grad_norms == ob.raw_grad_norms and not ob.skipped
+
+
+def test_module_forward_waits_for_a_pending_update():
+    """Readers inside the package order themselves against a deferred update: the module-level encoder forward right after a
+    train_step of an overlap_update Trainer sees the UPDATED weights (compared with the same call after a full synchronise)."""
+    tr, _, enc, _, _ = build_trainer(TINY, 2, overlap_update=True)
+    clips, me, mp = draw_batch(_gens(), 4, TINY, 11, 12)
+    cd, med, mpd = to_dev(clips, me, mp)
+    tr.train_step(cd, med, mpd, lr=1e-2, wd=0.0, ema=0.9)
+    with torch.no_grad():
+        z_now = [t.clone() for t in enc(cd, med)]
+        torch.cuda.synchronize()
+        tr.sync_update()
+        z_later = enc(cd, med)
+    for a, b in zip(z_now, z_later):
+        assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ guard bands
+BAND = 4096
+PATTERN = 0xA5
+
+
+class _GuardedWorkspaces:
+    """Replaces engine.chain.Workspace.get and hip.ops.Scratch.get by allocators that return EXACTLY the requested bytes from
+    the middle of a buffer whose first and last 4 KB hold a byte pattern; check() asserts both bands of every buffer."""
+
+    def __enter__(self):
+        from jepa_amd.engine import chain
+        from jepa_amd.hip import ops
+        self.chain, self.ops = chain, ops
+        self.bufs = {}
+        self.old_ws, self.old_sc = chain.Workspace.get, ops.Scratch.get
+
+        def alloc(key, nbytes, device):
+            nbytes = (int(nbytes) + 255) // 256 * 256
+            ent = self.bufs.get(key)
+            if ent is None or ent[1] != nbytes:
+                torch.cuda.synchronize()
+                if ent is not None:   # the buffer about to be replaced: its bands must be intact too
+                    assert bool((ent[0][:BAND] == PATTERN).all()) and bool((ent[0][BAND + ent[1]:] == PATTERN).all()), key
+                raw = torch.empty(nbytes + 2 * BAND, dtype=torch.uint8, device=device)
+                raw[:BAND] = PATTERN
+                raw[BAND + nbytes:] = PATTERN
+                ent = self.bufs[key] = (raw, nbytes)
+            return ent[0][BAND:BAND + nbytes]
+
+        def ws_get(tag, nbytes, device):
+            return alloc(("ws", tag), nbytes, device)
+
+        def sc_get(nbytes, device, tag="default", stream=None):
+            return alloc(("sc", tag, ops._raw_stream(torch.cuda.current_device()) if stream is None else stream), max(int(nbytes), 1 << 20), device)
+        chain.Workspace.get = staticmethod(ws_get)
+        ops.Scratch.get = staticmethod(sc_get)
+        return self
+
+    def check(self, what):
+        torch.cuda.synchronize()
+        for key, (raw, nbytes) in self.bufs.items():
+            head, tail = raw[:BAND], raw[BAND + nbytes:]
+            assert bool((head == PATTERN).all()), (what, key, "band BEFORE the workspace was written")
+            assert bool((tail == PATTERN).all()), (what, key, "band AFTER the workspace was written")
+
+    def __exit__(self, *a):
+        self.chain.Workspace.get, self.ops.Scratch.get = self.old_ws, self.old_sc
+        torch.cuda.synchronize()
+        self.bufs.clear()
+
+
+def _guard_check():
+    from jepa_amd.hip.lib import check, load_library
+    n, bad = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(load_library().vj_ws_guard_check(ctypes.byref(n), ctypes.byref(bad)), "vj_ws_guard_check")
+    return n.value, bad.value
+
+
+# (model, masks, batch, micro-batch, tile orders): the BASELINE model sizes at batches that keep the test in seconds; the benched
+# ViT-L batch itself with the default order and the two other families of orders
+GUARD_CASES = [
+    ("vitl_b24", VITL, VITL_MASKS, 24, None, (260, 0, 262)),
+    ("vitl_b4_orders", VITL, VITL_MASKS, 4, None,
+     (0, 1, 2, 3, 4, 5, 7, 8, 16, 33, 64, 128, 255, 256, 257, 258, 259, 260, 261, 262, 264, 272, 300, 383, 384, 400, 510, 511)),
+    ("vith_b6_micro3", VITH, VITL_MASKS, 6, 3, (260, 8, 511)),
+    ("vith384_b1", dict(VITH, crop=384, num_patches=4608), VITL_MASKS, 1, None, (260, 0)),
+    ("tiny_b2", TINY, TINY_MASKS[:1], 2, None, (260,)),
+]
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name,model,masks,B,micro,orders", GUARD_CASES, ids=[c[0] for c in GUARD_CASES])
+def test_chain_workspaces_stay_inside_their_guard_bands(name, model, masks, B, micro, orders):
+    """Two training steps (the second with different mask sizes, i.e. other sequence lengths in the same buffers) per tile order:
+    no 256-byte gap behind a workspace member (saved activations, backward temporaries, LayerNorm / attention / fc2-dgrad column
+    partials, split-K partials) and no 4 KB band around a workspace or a scratch buffer may change."""
+    from oracle import vjepa_oracle as O
+    with _opt("ws_guard", 1), _GuardedWorkspaces() as gw:
+        tr, _, _, _, _ = build_trainer(model, len(masks), micro_batch=micro, overlap_update=True)
+        gens = O.make_mask_gens(masks, model["crop"], model["frames"], model["patch"], model["tubelet"])
+        batches = [to_dev(*draw_batch(gens, B, model, 700 + i, 800 + i)) for i in range(2)]
+        for raster in orders:
+            with _opt("gemm_raster", raster):
+                for cd, med, mpd in batches:
+                    o = tr.train_step(cd, med, mpd, lr=1e-4, wd=0.04, ema=0.998)
+                tr.sync_update()
+                assert 0.05 < o.loss < 5.0 and not o.skipped, (name, raster, o.loss)
+                n, bad = _guard_check()
+                assert n > 0 and bad == 0, (name, raster, n, bad)
+                gw.check((name, raster))
+        del tr
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("M,N,K", [(5000, 1288, 256), (2304 + 40, 2600, 320)])
+def test_every_tile_order_of_the_persistent_gemm_inside_guard_bands(ops, M, N, K):
+    """ALL 512 values of option gemm_raster (csrc/options.cpp admits 0 ... 511) on shapes with >= 90 tiles (the persistent kernel's
+    threshold) whose last row AND column tile are shifted: outputs in the middle of poisoned buffers (plain, residual, GELU + saved derivative, fc2-dgrad + column partials);
+    every order must give the bits of order 0 and leave the 4 KB bands on both sides of every output untouched."""
+    g = torch.Generator(device=DEV).manual_seed(43)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    aux = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(torch.bfloat16)
+    nb = M * N * 2
+
+    def banded():
+        raw = torch.full((nb + 2 * BAND,), PATTERN, dtype=torch.uint8, device=DEV)
+        return raw, raw[BAND:BAND + nb].view(torch.bfloat16).view(M, N)
+
+    def run_all():
+        raws, outs = [], []
+        for kw in (dict(bias=bias), dict(bias=bias, residual=res), dict(bias=bias, epilogue=ops.EPI_GELU)):
+            raw, out = banded()
+            if kw.get("epilogue") == ops.EPI_GELU:
+                raw2, out2 = banded()
+                kw["aux_out"] = out2
+                raws.append(raw2)
+                outs.append(out2)
+            ops.gemm_nt(A, W, out=out, **kw)
+            raws.append(raw)
+            outs.append(out)
+        du, colpart = ops.gemm_dgelu_colsum(A, W, aux)
+        outs.append(du)
+        if colpart is not None:
+            outs.append(colpart)
+        torch.cuda.synchronize()
+        for raw in raws:
+            assert bool((raw[:BAND] == PATTERN).all()) and bool((raw[BAND + nb:] == PATTERN).all())
+        return outs
+    with _opt("gemm_raster", 0):
+        ref = run_all()
+    for raster in range(1, 512):
+        with _opt("gemm_raster", raster):
+            got = run_all()
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (raster, i, int((a != b).sum()))
+
+
+# ------------------------------------------------------------------------------------------ persistent two-workgroups-per-CU GEMM
+@pytest.mark.parametrize("M,N,K", [(5000, 1288, 256), (10560, 1024, 1024), (2304 + 40, 2600, 320), (37632, 384, 384), (1024, 384, 1536),
+                                   (256, 128, 192)])
+def test_persistent_4wave_gemm_is_bit_identical(ops, M, N, K):
+    """gemm_nt_4wp_kernel (flags 0x200: 256 x 128 tiles, 4 waves, two workgroups per CU walking tile lists, edge tiles shifted inside
+    the matrix) against the automatic selection -- same K loop arithmetic and epilogues, hence the same bits: plain + bias,
+    residual, GELU with and without the saved derivative, dGELU."""
+    g = torch.Generator(device=DEV).manual_seed(47)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    aux = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(torch.bfloat16)
+
+    def run_all(flags):
+        outs = [ops.gemm_nt(A, W, bias=bias, flags=flags), ops.gemm_nt(A, W, bias=bias, residual=res, flags=flags),
+                ops.gemm_nt(A, W, bias=bias, epilogue=ops.EPI_GELU, flags=flags)]
+        u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        outs.append(ops.gemm_nt(A, W, bias=bias, aux_out=u, epilogue=ops.EPI_GELU, flags=flags))
+        outs.append(u)
+        outs.append(ops.gemm_nt(A, W, aux_in=aux, epilogue=ops.EPI_DGELU, flags=flags))
+        torch.cuda.synchronize()
+        return outs
+    got = run_all(0x200)
+    refs = [run_all(0x100)]                 # the one-tile 4-wave kernel: the same K loop, any shape
+    if M * N >= 90 * 65536:
+        refs.append(run_all(0))             # the automatic selection = the persistent 8-phase kernel at >= 90 tiles of 256 x 256
+    for ref in refs:
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (i, int((a != b).sum()))

@@ -8,7 +8,8 @@ turns: round r runs `--steps` steps of arm 0, then arm 1, ... with a device sync
 per-arm median / min ms per step and the paired per-round delta against arm 0 (median, and how many rounds agree in sign).
 
     python tools/abab.py --arms "base;4w:gemm_4w=1;tn:wgrad_tn=1" --rounds 6 --steps 6
-host-side switches:  no_overlap=1 (single stream), overlap_fwd=0 (target forward on the main stream),
+host-side switches:  no_overlap=1 (single stream), overlap_fwd=0 (target forward on the main stream), upd_overlap=0 (the fused
+                     AdamW / EMA update on the main stream, as rounds 1-4 ran it),
                      tgt_flags=F (GEMM selection of the target encoder: flags | first block << 16, e.g. 786688 = 0x100 from block 12)
 """
 import argparse
@@ -43,7 +44,7 @@ def parse_arms(spec):
     return arms
 
 
-HOST_SWITCHES = ("no_overlap", "overlap_fwd", "tgt_flags")
+HOST_SWITCHES = ("no_overlap", "overlap_fwd", "tgt_flags", "upd_overlap")
 
 
 def main():
@@ -79,6 +80,8 @@ def main():
             set_option(k, opts.get(k, defaults[k]))
         side.enabled = not opts.get("no_overlap", 0)
         step_mod._OVERLAP_FWD = bool(opts.get("overlap_fwd", 1))
+        trainer.sync_update()
+        trainer.overlap_update = bool(opts.get("upd_overlap", 1))   # fused update on its own stream, range by range (Trainer(overlap_update=))
         step_mod._TGT_GEMM_FLAGS = int(opts.get("tgt_flags", 0))   # vj_blocks_fwd gemm_flags of the target encoder (flags | first block << 16)
 
     def run_steps(n, first=0):
