@@ -877,59 +877,64 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
       else dma.template issue<false>(qbase, rs, dobase, os, (t + 1) * 64, S, smem + ((t + 1) & 1) * BUFB);
     }
 
-    float pv[KT][4][4], dsv[KT][4][4];
-#pragma unroll
-    for (int qt = 0; qt < 4; qt++) {
-      const float4 lse4 = *(const float4*)(lse_s + qt * 16 + 4 * g);   // queries qt*16 + 4g + {0..3}
-      const float4 ndl4 = *(const float4*)(dl_s + qt * 16 + 4 * g);    // -delta of the same queries
-      // the dP accumulator STARTS at -delta[q] (this lane's four rows): dP - delta comes out of the matrix pipe
-      // SM: the score accumulator starts at -lse2[q] the same way, so P = exp2(accumulator) (padded queries: -inf -> P = 0)
-      f32x4_t sacc[KT], dpacc[KT];
-#pragma unroll
-      for (int kt = 0; kt < KT; kt++) {
-        sacc[kt] = SM ? (f32x4_t){-lse4.x, -lse4.y, -lse4.z, -lse4.w} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        dpacc[kt] = (f32x4_t){ndl4.x, ndl4.y, ndl4.z, ndl4.w};
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ks++) {
-        const bf16x8_t qa = RowTile<HDP>::frag(q_lds, qt * 16 + li, ks * 4 + g);     // read ONCE for all KT key tiles
-        const bf16x8_t da = RowTile<HDP>::frag(do_lds, qt * 16 + li, ks * 4 + g);
-#pragma unroll
-        for (int kt = 0; kt < KT; kt++) {
-          sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], sacc[kt], 0, 0, 0);
-          dpacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dpacc[kt], 0, 0, 0);
-        }
-      }
-      const f32x2_t nl[2] = {{-lse4.x, -lse4.y}, {-lse4.z, -lse4.w}};
-#pragma unroll
-      for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
-          const f32x2_t sv = {sacc[kt][2 * hf], sacc[kt][2 * hf + 1]}, dpv = {dpacc[kt][2 * hf], dpacc[kt][2 * hf + 1]};
-          f32x2_t a = sv;
-          if constexpr (!SM) a = __builtin_elementwise_fma(sv, sc2, nl[hf]);   // padded queries: lse = +inf -> P = 0
-          const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          const f32x2_t ds = e * dpv;
-          pv[kt][qt][2 * hf] = e[0];
-          pv[kt][qt][2 * hf + 1] = e[1];
-          dsv[kt][qt][2 * hf] = ds[0];
-          dsv[kt][qt][2 * hf + 1] = ds[1];
-        }
-    }
+    // Two halves of the 64-query tile (c = 0, 1: queries 32c .. 32c+31 = the contraction chunk of one transposed MFMA): S / dP / P / dS of
+    // a half, then its dV / dK MFMAs.  Per accumulator the operations and their order are those of the round-4 form (all four
+    // 16-query blocks first, then both halves) -- bit-identical -- but only one half's P / dS is live at a time, which is what lets
+    // KT = 4 (64 keys per wave: every Q / dO fragment, transposed read and statistics read serves FOUR key tiles) fit the registers.
 #pragma unroll
     for (int c = 0; c < 2; c++) {
+      float pv[KT][2][4], dsv[KT][2][4];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; q2++) {
+        const int qt = 2 * c + q2;
+        const float4 lse4 = *(const float4*)(lse_s + qt * 16 + 4 * g);   // queries qt*16 + 4g + {0..3}
+        const float4 ndl4 = *(const float4*)(dl_s + qt * 16 + 4 * g);    // -delta of the same queries
+        // the dP accumulator STARTS at -delta[q] (this lane's four rows): dP - delta comes out of the matrix pipe
+        // SM: the score accumulator starts at -lse2[q] the same way, so P = exp2(accumulator) (padded queries: -inf -> P = 0)
+        f32x4_t sacc[KT], dpacc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+          sacc[kt] = SM ? (f32x4_t){-lse4.x, -lse4.y, -lse4.z, -lse4.w} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          dpacc[kt] = (f32x4_t){ndl4.x, ndl4.y, ndl4.z, ndl4.w};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+          const bf16x8_t qa = RowTile<HDP>::frag(q_lds, qt * 16 + li, ks * 4 + g);     // read ONCE for all KT key tiles
+          const bf16x8_t da = RowTile<HDP>::frag(do_lds, qt * 16 + li, ks * 4 + g);
+#pragma unroll
+          for (int kt = 0; kt < KT; kt++) {
+            sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], sacc[kt], 0, 0, 0);
+            dpacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dpacc[kt], 0, 0, 0);
+          }
+        }
+        const f32x2_t nl[2] = {{-lse4.x, -lse4.y}, {-lse4.z, -lse4.w}};
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
+            const f32x2_t sv = {sacc[kt][2 * hf], sacc[kt][2 * hf + 1]}, dpv = {dpacc[kt][2 * hf], dpacc[kt][2 * hf + 1]};
+            f32x2_t a = sv;
+            if constexpr (!SM) a = __builtin_elementwise_fma(sv, sc2, nl[hf]);   // padded queries: lse = +inf -> P = 0
+            const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+            const f32x2_t ds = e * dpv;
+            pv[kt][q2][2 * hf] = e[0];
+            pv[kt][q2][2 * hf + 1] = e[1];
+            dsv[kt][q2][2 * hf] = ds[0];
+            dsv[kt][q2][2 * hf + 1] = ds[1];
+          }
+      }
       bf16x8_t pfr[KT], dfr[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; kt++) {
         u32x4_t pw, dw;
-        pw[0] = cvt_pk_bf16(pv[kt][2 * c][0], pv[kt][2 * c][1]);
-        pw[1] = cvt_pk_bf16(pv[kt][2 * c][2], pv[kt][2 * c][3]);
-        pw[2] = cvt_pk_bf16(pv[kt][2 * c + 1][0], pv[kt][2 * c + 1][1]);
-        pw[3] = cvt_pk_bf16(pv[kt][2 * c + 1][2], pv[kt][2 * c + 1][3]);
-        dw[0] = cvt_pk_bf16(dsv[kt][2 * c][0], dsv[kt][2 * c][1]);
-        dw[1] = cvt_pk_bf16(dsv[kt][2 * c][2], dsv[kt][2 * c][3]);
-        dw[2] = cvt_pk_bf16(dsv[kt][2 * c + 1][0], dsv[kt][2 * c + 1][1]);
-        dw[3] = cvt_pk_bf16(dsv[kt][2 * c + 1][2], dsv[kt][2 * c + 1][3]);
+        pw[0] = cvt_pk_bf16(pv[kt][0][0], pv[kt][0][1]);
+        pw[1] = cvt_pk_bf16(pv[kt][0][2], pv[kt][0][3]);
+        pw[2] = cvt_pk_bf16(pv[kt][1][0], pv[kt][1][1]);
+        pw[3] = cvt_pk_bf16(pv[kt][1][2], pv[kt][1][3]);
+        dw[0] = cvt_pk_bf16(dsv[kt][0][0], dsv[kt][0][1]);
+        dw[1] = cvt_pk_bf16(dsv[kt][0][2], dsv[kt][0][3]);
+        dw[2] = cvt_pk_bf16(dsv[kt][1][0], dsv[kt][1][1]);
+        dw[3] = cvt_pk_bf16(dsv[kt][1][2], dsv[kt][1][3]);
         pfr[kt] = __builtin_bit_cast(bf16x8_t, pw);
         dfr[kt] = __builtin_bit_cast(bf16x8_t, dw);
       }
@@ -1015,7 +1020,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 //   delta[q] = sum_d dO[q,d] O[q,d] (the softmax-backward row term) is computed HERE, from the dO fragments the wave holds
 //   anyway plus one read of its O rows, and written to `delta` for the dK/dV kernel, which is launched after this one:
 //   the separate delta pass (one more kernel on the critical path of every attention backward) is gone.
-template <int HDP, bool SM>
+// QW = 16-query tiles per wave (2: 128 queries per workgroup, the form of rounds 2-4; 4: 256 -- every K / V fragment, every transposed
+// K read of a key tile then serves four query tiles: the kernel is bound by LDS instruction count at head_dim 24, see the dK/dV kernel)
+template <int HDP, bool SM, int QW = 2>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv_all,
                                                           const bf16_t* __restrict__ o_all,
                                                           const bf16_t* __restrict__ dout_all,
@@ -1049,12 +1056,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
   const bf16_t* dobase = dout + (int64_t)b * S * os + (int64_t)h * hd;
   const bf16_t* obase = o + (int64_t)b * S * os + (int64_t)h * hd;
-  const int q0 = qb * 128 + w * 32;
+  const int q0 = qb * (64 * QW) + w * (16 * QW);
 
-  bf16x8_t qf[2][KS], dof[2][KS];
-  float lse_q[2], dl_q[2];
+  bf16x8_t qf[QW][KS], dof[QW][KS];
+  float lse_q[QW], dl_q[QW];
 #pragma unroll
-  for (int qt = 0; qt < 2; qt++) {
+  for (int qt = 0; qt < QW; qt++) {
     const int q = q0 + qt * 16 + li;
     float dsum = 0.f;   // this lane's share of delta[q]: head-dim chunks 8g .. 8g+7 of every 32-wide step
 #pragma unroll
@@ -1079,16 +1086,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       for (int ks = 0; ks < KS; ks++) qf[qt][ks] = scale_frag(qf[qt][ks], sc);
     }
   }
-  f32x4_t dqacc[2][DT];
+  f32x4_t dqacc[QW][DT];
 #pragma unroll
-  for (int qt = 0; qt < 2; qt++)
+  for (int qt = 0; qt < QW; qt++)
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) dqacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  f32x4_t ndl4[2];   // -delta[q] of this lane's query, four times: the seed of every dP accumulator block
-  f32x4_t nls4[2];   // SM: -lse2[q] four times: the seed of every score accumulator block (padded queries: -inf -> P = 0)
+  f32x4_t ndl4[QW];   // -delta[q] of this lane's query, four times: the seed of every dP accumulator block
+  f32x4_t nls4[QW];   // SM: -lse2[q] four times: the seed of every score accumulator block (padded queries: -inf -> P = 0)
 #pragma unroll
-  for (int qt = 0; qt < 2; qt++) {
+  for (int qt = 0; qt < QW; qt++) {
     ndl4[qt] = (f32x4_t){-dl_q[qt], -dl_q[qt], -dl_q[qt], -dl_q[qt]};
     nls4[qt] = SM ? (f32x4_t){-lse_q[qt], -lse_q[qt], -lse_q[qt], -lse_q[qt]} : (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
@@ -1115,76 +1122,78 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     }
     cur_off = cur_off + BUFB == RINGB ? 0 : cur_off + BUFB;
     nxt_off = nxt_off + BUFB == RINGB ? 0 : nxt_off + BUFB;
-    f32x4_t sacc[2][4], dpacc[2][4];
+    // Two halves of the 64-key tile (c = 0, 1: keys 32c .. 32c+31 = the contraction chunk of one dQ MFMA): S^T / dP^T / dS^T of a half
+    // for all QW query tiles, then its dQ MFMAs.  Per accumulator the same operations in the same order as the round-4 form (all
+    // four key blocks first, then both halves): bit-identical; only one half's scores are live, which is what lets QW = 4 fit.
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++)
+    for (int c = 0; c < 2; c++) {
+      f32x4_t sacc[QW][2], dpacc[QW][2];
 #pragma unroll
-      for (int kt = 0; kt < 4; kt++) {
-        sacc[qt][kt] = nls4[qt];    // zeros, or (SM) -lse2[q]: s - lse comes out of the matrix pipe
-        dpacc[qt][kt] = ndl4[qt];   // the dP accumulators start at -delta[q]: dP - delta comes out of the matrix pipe
-      }
+      for (int qt = 0; qt < QW; qt++)
 #pragma unroll
-    for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-      for (int ks = 0; ks < KS; ks++) {
-        const bf16x8_t ka = RowTile<HDP>::frag(k_lds, kt * 16 + li, ks * 4 + g);
-        const bf16x8_t va = RowTile<HDP>::frag(v_lds, kt * 16 + li, ks * 4 + g);
-#pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
-          sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qt][ks], sacc[qt][kt], 0, 0, 0);
-          dpacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qt][ks], dpacc[qt][kt], 0, 0, 0);
+        for (int k2 = 0; k2 < 2; k2++) {
+          sacc[qt][k2] = nls4[qt];    // zeros, or (SM) -lse2[q]: s - lse comes out of the matrix pipe
+          dpacc[qt][k2] = ndl4[qt];   // the dP accumulators start at -delta[q]: dP - delta comes out of the matrix pipe
         }
-      }
-    bf16x8_t dsf[2][2];
-    // dS^T = P^T (dP^T - delta)
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
-      const f32x2_t nl = {-lse_q[qt], -lse_q[qt]};
+      for (int k2 = 0; k2 < 2; k2++)
 #pragma unroll
-      for (int kt = 0; kt < 4; kt++)
+        for (int ks = 0; ks < KS; ks++) {
+          const int kt = 2 * c + k2;
+          const bf16x8_t ka = RowTile<HDP>::frag(k_lds, kt * 16 + li, ks * 4 + g);
+          const bf16x8_t va = RowTile<HDP>::frag(v_lds, kt * 16 + li, ks * 4 + g);
 #pragma unroll
-        for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
-          const f32x2_t sv = {sacc[qt][kt][2 * hf], sacc[qt][kt][2 * hf + 1]};
-          const f32x2_t dpv = {dpacc[qt][kt][2 * hf], dpacc[qt][kt][2 * hf + 1]};
-          f32x2_t a = sv;
-          if constexpr (!SM) a = __builtin_elementwise_fma(sv, sc2, nl);
-          const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          const f32x2_t ds = e * dpv;
-          sacc[qt][kt][2 * hf] = ds[0];
-          sacc[qt][kt][2 * hf + 1] = ds[1];
+          for (int qt = 0; qt < QW; qt++) {
+            sacc[qt][k2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[qt][ks], sacc[qt][k2], 0, 0, 0);
+            dpacc[qt][k2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[qt][ks], dpacc[qt][k2], 0, 0, 0);
+          }
         }
-    }
-    if (k0 + 64 > S) {   // wave-uniform, last tile only: padded keys re-read key S-1, their dS must vanish
-      asm volatile("" ::: "memory");   // keeps this a real branch (the kernel is VALU-bound; an if-converted mask costs ~30 %)
+      // dS^T = P^T (dP^T - delta)
 #pragma unroll
-      for (int qt = 0; qt < 2; qt++)
+      for (int qt = 0; qt < QW; qt++) {
+        const f32x2_t nl = {-lse_q[qt], -lse_q[qt]};
 #pragma unroll
-        for (int kt = 0; kt < 4; kt++)
+        for (int k2 = 0; k2 < 2; k2++)
 #pragma unroll
-          for (int r = 0; r < 4; r++)
-            if (k0 + kt * 16 + 4 * g + r >= S) sacc[qt][kt][r] = 0.f;
-    }
+          for (int hf = 0; hf < 2; hf++) {   // 2-vectors: v_pk_fma_f32 / v_pk_mul_f32
+            const f32x2_t sv = {sacc[qt][k2][2 * hf], sacc[qt][k2][2 * hf + 1]};
+            const f32x2_t dpv = {dpacc[qt][k2][2 * hf], dpacc[qt][k2][2 * hf + 1]};
+            f32x2_t a = sv;
+            if constexpr (!SM) a = __builtin_elementwise_fma(sv, sc2, nl);
+            const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+            const f32x2_t ds = e * dpv;
+            sacc[qt][k2][2 * hf] = ds[0];
+            sacc[qt][k2][2 * hf + 1] = ds[1];
+          }
+      }
+      if (k0 + 64 > S) {   // wave-uniform, last tile only: padded keys re-read key S-1, their dS must vanish
+        asm volatile("" ::: "memory");   // keeps this a real branch (the kernel is VALU-bound; an if-converted mask costs ~30 %)
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
+        for (int qt = 0; qt < QW; qt++)
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
+          for (int k2 = 0; k2 < 2; k2++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (k0 + (2 * c + k2) * 16 + 4 * g + r >= S) sacc[qt][k2][r] = 0.f;
+      }
+      bf16x8_t dsf[QW];
+#pragma unroll
+      for (int qt = 0; qt < QW; qt++) {
         u32x4_t dw;
-        dw[0] = cvt_pk_bf16(sacc[qt][2 * c][0], sacc[qt][2 * c][1]);
-        dw[1] = cvt_pk_bf16(sacc[qt][2 * c][2], sacc[qt][2 * c][3]);
-        dw[2] = cvt_pk_bf16(sacc[qt][2 * c + 1][0], sacc[qt][2 * c + 1][1]);
-        dw[3] = cvt_pk_bf16(sacc[qt][2 * c + 1][2], sacc[qt][2 * c + 1][3]);
-        dsf[qt][c] = __builtin_bit_cast(bf16x8_t, dw);
+        dw[0] = cvt_pk_bf16(sacc[qt][0][0], sacc[qt][0][1]);
+        dw[1] = cvt_pk_bf16(sacc[qt][0][2], sacc[qt][0][3]);
+        dw[2] = cvt_pk_bf16(sacc[qt][1][0], sacc[qt][1][1]);
+        dw[3] = cvt_pk_bf16(sacc[qt][1][2], sacc[qt][1][3]);
+        dsf[qt] = __builtin_bit_cast(bf16x8_t, dw);
       }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; c++)
 #pragma unroll
       for (int dt = 0; dt < DT; dt++) {
         const bf16x8_t ktf = trf.load(k_lds, c * 32, dt * 16);
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++)
-          dqacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt][c], dqacc[qt][dt], 0, 0, 0);
+        for (int qt = 0; qt < QW; qt++)
+          dqacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qt], dqacc[qt][dt], 0, 0, 0);
       }
+    }
   }
 
   // column partials for the qkv bias gradient (colq != nullptr): this workgroup's sum over its 128 queries of dQ (fp32, before the
@@ -1194,7 +1203,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
     for (int dt = 0; dt < DT; dt++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) cq[dt][r] = row16_sum(dqacc[0][dt][r] + dqacc[1][dt][r]);
+      for (int r = 0; r < 4; r++) {
+        float a = dqacc[0][dt][r] + dqacc[1][dt][r];
+        if constexpr (QW == 4) a = a + dqacc[2][dt][r] + dqacc[3][dt][r];
+        cq[dt][r] = row16_sum(a);
+      }
     raw_barrier();   // every wave is done with the {K, V} ring: its first 4 x HDP floats become the combine buffer
     float* red = (float*)smem;
     if (li == 0) {
@@ -1208,7 +1221,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         (red[tid] + red[HDP + tid] + red[2 * HDP + tid] + red[3 * HDP + tid]) * scale;
   }
 #pragma unroll
-  for (int qt = 0; qt < 2; qt++) {
+  for (int qt = 0; qt < QW; qt++) {
     const int q = q0 + qt * 16 + li;
     if (q < S) {
       bf16_t* dqp = dqkv + ((int64_t)b * S + q) * rs + (int64_t)h * hd;
@@ -1367,15 +1380,17 @@ extern "C" int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H) { retur
 static int dkdv_kt(int64_t hd) {
   const int kt_opt = vj_opt(VJ_OPT_ATTN_DKDV_KT);
   switch (pick_hdp(hd)) {
-    case 32: return kt_opt == 1 ? 1 : 2;
+    case 32: return kt_opt == 1 ? 1 : (kt_opt == 4 ? 4 : 2);
     case 64: return kt_opt == 2 ? 2 : 1;
     default: return 1;
   }
 }
+// dQ tiling of the current options: 16-query tiles per wave (option attn_dq_qw: 0 = 2 everywhere; 4 = four at head_dim <= 32)
+static int dq_qw(int64_t hd) { return (vj_opt(VJ_OPT_ATTN_DQ_QW) == 4 && pick_hdp(hd) == 32) ? 4 : 2; }
 // rows of the column-partial matrices vj_attn_bwd_colsum writes for one [B, S] segment: colq [rows_q][H*hd], colkv [rows_kv][2*H*hd]
 extern "C" int vj_attn_bwd_colsum_rows(int64_t B, int64_t S, int64_t hd, int64_t* rows_q, int64_t* rows_kv) {
   VJ_CHECK_ARG(rows_q != nullptr && rows_kv != nullptr && hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_bwd_colsum_rows: bad arguments");
-  *rows_q = B * cdiv64(S, 128);
+  *rows_q = B * cdiv64(S, 64 * dq_qw(hd));
   *rows_kv = B * cdiv64(S, 64 * dkdv_kt(hd));
   return 0;
 }
@@ -1391,7 +1406,8 @@ extern "C" int vj_attn_bwd_segs(const void* qkv, const void* o, const void* dout
   const int kt = dkdv_kt(hd);
   AttnSegs sq, sk;
   int64_t gq = 0, gk = 0;
-  if (int rc = make_segs(segs, n_segs, H, 128, &sq, &gq, "vj_attn_bwd")) return rc;
+  const int qw = dq_qw(hd);
+  if (int rc = make_segs(segs, n_segs, H, 64 * qw, &sq, &gq, "vj_attn_bwd")) return rc;
   if (int rc = make_segs(segs, n_segs, H, 64 * kt, &sk, &gk, "vj_attn_bwd")) return rc;
   if (gq == 0) return 0;
   int64_t rows_end = 0;   // the delta workspace mirrors lse2: H floats per token row up to the last row of the list
@@ -1410,9 +1426,14 @@ extern "C" int vj_attn_bwd_segs(const void* qkv, const void* o, const void* dout
   // dK/dV: KTV 16-key tiles per wave (option attn_dkdv_kt: 0 = per head-dim class, 1 / 2 forced)
 #define VJ_BWD_LAUNCH(HDPV, KTV, SMV)                                                                              \
   do {                                                                                                             \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, SMV>), dim3((unsigned)gq), dim3(256), 0, stream,                  \
-                       (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sq,   \
-                       (int)H, (int)hd, sc, sabs, colq);                                                           \
+    if (HDPV == 32 && qw == 4)                                                                                     \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV == 32 ? 32 : HDPV, SMV, HDPV == 32 ? 4 : 2>), dim3((unsigned)gq), dim3(256), 0, stream, \
+                         (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sq, \
+                         (int)H, (int)hd, sc, sabs, colq);                                                         \
+    else                                                                                                           \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, SMV, 2>), dim3((unsigned)gq), dim3(256), 0, stream,              \
+                         (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sq, \
+                         (int)H, (int)hd, sc, sabs, colq);                                                         \
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV, SMV>), dim3((unsigned)gk), dim3(256), 0, stream,            \
                        (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sk, (int)H, (int)hd,    \
                        sc, kscale, colkv);                                                                         \
@@ -1424,7 +1445,7 @@ extern "C" int vj_attn_bwd_segs(const void* qkv, const void* o, const void* dout
   } while (0)
   const bool sm = vj_opt(VJ_OPT_ATTN_SOFTMAX) != 0;
   switch (pick_hdp(hd)) {
-    case 32: if (kt == 1) VJ_BWD_SM(32, 1); else VJ_BWD_SM(32, 2); break;
+    case 32: if (kt == 1) VJ_BWD_SM(32, 1); else if (kt == 4) VJ_BWD_SM(32, 4); else VJ_BWD_SM(32, 2); break;
     case 64: if (kt == 2) VJ_BWD_SM(64, 2); else VJ_BWD_SM(64, 1); break;
     case 96: VJ_BWD_SM(96, 1); break;
     default: VJ_BWD_SM(128, 1);

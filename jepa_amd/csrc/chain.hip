@@ -49,7 +49,54 @@ static inline int64_t pad64i(int64_t m) { return (m + 63) / 64 * 64; }
 static inline int64_t guard_gap() { return vj_opt(VJ_OPT_WS_GUARD) ? GUARD_BYTES : 0; }
 namespace {
 std::mutex g_guard_mu;
-std::vector<char*> g_guards;   // device addresses of the gaps poisoned so far (deduplicated at check time)
+std::vector<char*> g_guards;   // device addresses of the gaps poisoned and not yet inspected
+int64_t g_guard_checked = 0, g_guard_bad = 0;
+char* g_guard_first_bad = nullptr;
+
+// inspect (and forget) the recorded gaps inside [lo, hi); the device must be idle.  Caller holds g_guard_mu.
+int inspect_gaps(char* lo, char* hi) {
+  std::sort(g_guards.begin(), g_guards.end());
+  g_guards.erase(std::unique(g_guards.begin(), g_guards.end()), g_guards.end());
+  std::vector<char*> keep;
+  unsigned char host[GUARD_BYTES];
+  for (char* p : g_guards) {
+    if (p < lo || p >= hi) {
+      keep.push_back(p);
+      continue;
+    }
+    hipError_t e = hipMemcpy(host, p, GUARD_BYTES, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      vj_set_error("ws_guard: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    bool bad = false;
+    for (int i = 0; i < GUARD_BYTES; i++) bad |= host[i] != GUARD_PATTERN;
+    g_guard_checked++;
+    if (bad) {
+      if (g_guard_bad == 0) g_guard_first_bad = p;
+      g_guard_bad++;
+    }
+  }
+  g_guards.swap(keep);
+  return 0;
+}
+
+// A chain call is about to lay ITS members (and gaps) over [ws, ws + bytes): gaps recorded there by earlier calls belong to an
+// older layout (another trunk sharing the temporary workspace, other sequence lengths) and are about to be overwritten
+// legitimately -- inspect them now (device-wide synchronise: this is a diagnostic mode), then forget them.
+int guard_begin(void* ws, int64_t bytes) {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  bool any = false;
+  for (char* p : g_guards) any |= (p >= (char*)ws && p < (char*)ws + bytes);
+  if (!any) return 0;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    vj_set_error("ws_guard: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return inspect_gaps((char*)ws, (char*)ws + bytes);
+}
+
 int poison_gap(char* p, hipStream_t st) {
   hipError_t e = hipMemsetAsync(p, GUARD_PATTERN, GUARD_BYTES, st);
   if (e != hipSuccess) {
@@ -62,7 +109,8 @@ int poison_gap(char* p, hipStream_t st) {
 }
 }  // namespace
 
-// -> number of damaged gaps (>= 0) in *n_bad, number of distinct gaps inspected in *n_checked; forgets the recorded gaps
+// -> gaps inspected since the last call in *n_checked, those that no longer held the pattern in *n_bad; synchronises the device,
+// inspects every gap still recorded and resets the counters
 extern "C" int vj_ws_guard_check(int64_t* n_checked, int64_t* n_bad) {
   VJ_CHECK_ARG(n_checked != nullptr && n_bad != nullptr, "vj_ws_guard_check: null output");
   hipError_t e = hipDeviceSynchronize();
@@ -71,25 +119,12 @@ extern "C" int vj_ws_guard_check(int64_t* n_checked, int64_t* n_bad) {
     return (int)e;
   }
   std::lock_guard<std::mutex> lk(g_guard_mu);
-  std::sort(g_guards.begin(), g_guards.end());
-  g_guards.erase(std::unique(g_guards.begin(), g_guards.end()), g_guards.end());
-  *n_checked = (int64_t)g_guards.size();
-  *n_bad = 0;
-  unsigned char host[GUARD_BYTES];
-  for (char* p : g_guards) {
-    e = hipMemcpy(host, p, GUARD_BYTES, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) {
-      vj_set_error("vj_ws_guard_check: %s", hipGetErrorString(e));
-      return (int)e;
-    }
-    bool bad = false;
-    for (int i = 0; i < GUARD_BYTES; i++) bad |= host[i] != GUARD_PATTERN;
-    if (bad) {
-      if (*n_bad == 0) vj_set_error("vj_ws_guard_check: first damaged gap at device address %p", (void*)p);
-      *n_bad += 1;
-    }
-  }
-  g_guards.clear();
+  if (int rc = inspect_gaps(nullptr, (char*)UINTPTR_MAX)) return rc;
+  *n_checked = g_guard_checked;
+  *n_bad = g_guard_bad;
+  if (g_guard_bad) vj_set_error("vj_ws_guard_check: %ld damaged gaps, the first at device address %p", (long)g_guard_bad, (void*)g_guard_first_bad);
+  g_guard_checked = g_guard_bad = 0;
+  g_guard_first_bad = nullptr;
   return 0;
 }
 
@@ -295,6 +330,7 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
   VJ_CHECK_ARG(((uintptr_t)ws & 255) == 0, "vj_blocks_fwd: workspace must be 256-byte aligned");
   const FwdLayout L = fwd_layout(M, D, Dh, heads);
   if (L.n_gap) {   // option ws_guard
+    CH(guard_begin(ws, vj_blocks_fwd_ws_bytes(M, D, Dh, heads, n_blocks, save)));
     for (int64_t li = 0; li < (save ? n_blocks : 1); li++)
       for (int k = 0; k < L.n_gap; k++) CH(poison_gap((char*)ws + li * L.total + L.gap[k], stream));
     if (!save) CH(poison_gap((char*)ws + L.total + al256(M * D * 2), stream));
@@ -510,7 +546,8 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
   }
   const char* sv = (const char*)save_ws;
   char* tmp = (char*)tmp_ws;
-  for (int k = 0; k < L.n_gap; k++) CH(poison_gap(tmp + L.gap[k], stream));   // option ws_guard
+  if (L.n_gap) CH(guard_begin(tmp, L.total));   // option ws_guard
+  for (int k = 0; k < L.n_gap; k++) CH(poison_gap(tmp + L.gap[k], stream));
   SideCtx sc{stream, side ? side : stream, tmp, &L, M, alpha, beta_acc, ((flags & 1) || vj_opt(VJ_OPT_WGRAD_TN)) ? 1 : 0};
   constexpr int MAX_BLOCKS = 256;
   VJ_CHECK_ARG(n_blocks <= MAX_BLOCKS, "vj_blocks_bwd: more than %d blocks", MAX_BLOCKS);

@@ -23,7 +23,7 @@ enum VjOpt {
   VJ_OPT_WGRAD_GROUP,          // 1 (default): the four weight gradients of a block in ONE launch (vj_gemm_bf16_tn_grouped);
                                // 0: one launch each (different fp32 summation order: results agree to rounding, not bitwise)
   VJ_OPT_WGRAD_SLOW_ISSUE,     // 1: the TN kernel's K loop issues its parts through the generic address path (A/B only)
-  VJ_OPT_ATTN_DKDV_KT,         // 16-key tiles per wave in the attention dK/dV kernel: 0 (default) per head-dim class, 1 / 2 forced
+  VJ_OPT_ATTN_DKDV_KT,         // 16-key tiles per wave in the attention dK/dV kernel: 0 (default) per head-dim class, 1 / 2 forced, 4 (round 5) at head_dim <= 32
   VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)
   VJ_OPT_ATTN_SOFTMAX,         // 1 (A/B only): attention kernels with the soft-max scale folded into the stationary operand
                                // and the score accumulators seeded with -max / -lse (no per-score FMA, no per-tile row maximum).  With a
@@ -54,6 +54,10 @@ enum VjOpt {
                                // are still 8 rows x 4 columns, but its band walks down the rows of one column group, so the B panels stay in its L2 and
                                // every A panel streams through once per column group: fabric reads of the encoder shapes -14 ... -38 %, step -0.6 ... -0.8 ms
                                // (profiles/r04_gemm_raster.md).  0 = the order of rounds 2-4 (groups of 8 row tiles).  Bit-identical results
+  VJ_OPT_ATTN_DQ_QW,           // 16-query tiles per wave in the attention dQ kernel: 0 (default) = 2 (128 queries per workgroup); 4 = four at head_dim <= 32
+                               // (256 queries per workgroup: half the LDS instructions per MFMA).  dqkv bit-identical; the dQ column partials regroup
+  VJ_OPT_ADAM_GRID,            // cap on the workgroup count of the guarded fused AdamW / EMA kernel (0 = none: 8 workgroups per CU); A/B of the
+                               // range-wise update running beside the next step's forward (Trainer(overlap_update)).  Same results
   VJ_OPT_WS_GUARD,             // diagnostics: 1 = 256-byte guard gaps behind every member of the chain workspaces, poisoned by the chain calls and
                                // inspected by vj_ws_guard_check (tests/test_round5_gpu.py).  Changes the workspace sizes: set it before the first step
   VJ_OPT_COUNT

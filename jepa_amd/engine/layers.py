@@ -47,6 +47,26 @@ class SideStream:
         torch.cuda.current_stream().wait_stream(self.stream)
 
 
+def low_priority_stream(device):
+    """A HIP stream of the LOWEST priority the device offers (torch.cuda.Stream only reaches the default and higher ones), wrapped
+    for torch: the workgroups of the deferred fused update should take CUs only where the two forward streams leave them.
+    Falls back to a plain stream when the runtime call is unavailable."""
+    import ctypes
+    dev = torch.device(device)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+        with torch.cuda.device(dev):
+            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+                raise OSError("hipDeviceGetStreamPriorityRange")
+            h = ctypes.c_void_p()
+            if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, least.value) != 0 or not h.value:   # 1 = hipStreamNonBlocking
+                raise OSError("hipStreamCreateWithPriority")
+        return torch.cuda.ExternalStream(h.value, device=dev)
+    except (OSError, AttributeError):
+        return torch.cuda.Stream(device=dev)
+
+
 _SIDE = {}
 
 

@@ -22,7 +22,7 @@ from ..hip import ops
 import weakref
 
 from . import chain, dp, optstate
-from .layers import encoder_backward, encoder_forward, predictor_backward, predictor_forward, side_stream
+from .layers import encoder_backward, encoder_forward, low_priority_stream, predictor_backward, predictor_forward, side_stream
 from . import weights as _weights
 from .weights import ParamArena, bump_generation, encoder_views, is_no_decay, predictor_views
 
@@ -104,6 +104,7 @@ class StepOutput:
 
 import os as _os
 _OVERLAP_FWD = _os.environ.get("VJ_OVERLAP_FWD", "1") != "0"   # diagnostics: 0 = target forward on the main stream
+_UPD_LOW_PRIO = _os.environ.get("VJ_UPD_LOW_PRIO", "0") == "1"   # the deferred update's stream at the device's lowest priority (A/B)
 # GEMM kernel selection of the EMA target encoder's forward (vj_blocks_fwd gemm_flags: low 16 bits = flags, bits 16-23 = first
 # block they apply to); 0 = automatic everywhere
 _TGT_GEMM_FLAGS = int(_os.environ.get("VJ_TGT_GEMM_FLAGS", "0"), 0)
@@ -398,7 +399,7 @@ class Trainer:
             ready = torch.cuda.Event()
             ready.record(main)          # gradients, norms and the step count are final
             if self._upd_stream is None:
-                self._upd_stream = torch.cuda.Stream(device=self.device)
+                self._upd_stream = (low_priority_stream(self.device) if _UPD_LOW_PRIO else torch.cuda.Stream(device=self.device))
             upd = self._upd_stream
             upd.wait_event(ready)
             gates = {"enc": [], "pred": []}

@@ -44,7 +44,7 @@ def parse_arms(spec):
     return arms
 
 
-HOST_SWITCHES = ("no_overlap", "overlap_fwd", "tgt_flags", "upd_overlap")
+HOST_SWITCHES = ("no_overlap", "overlap_fwd", "tgt_flags", "upd_overlap", "upd_prio")
 
 
 def main():
@@ -81,7 +81,11 @@ def main():
         side.enabled = not opts.get("no_overlap", 0)
         step_mod._OVERLAP_FWD = bool(opts.get("overlap_fwd", 1))
         trainer.sync_update()
-        trainer.overlap_update = bool(opts.get("upd_overlap", 1))   # fused update on its own stream, range by range (Trainer(overlap_update=))
+        trainer.overlap_update = bool(opts.get("upd_overlap", 1))
+        lowp = bool(opts.get("upd_prio", 0))                        # 1: the update stream at the device's lowest priority
+        if lowp != getattr(trainer, "_upd_lowp", False):
+            torch.cuda.synchronize()
+            step_mod._UPD_LOW_PRIO, trainer._upd_stream, trainer._upd_lowp = lowp, None, lowp   # fused update on its own stream, range by range (Trainer(overlap_update=))
         step_mod._TGT_GEMM_FLAGS = int(opts.get("tgt_flags", 0))   # vj_blocks_fwd gemm_flags of the target encoder (flags | first block << 16)
 
     def run_steps(n, first=0):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--shapes", default="")
     ap.add_argument("--fwd-qt", type=int, default=2)
     ap.add_argument("--sm", default="", help="comma list of attn_softmax option values to run one after the other (e.g. 0,1)")
+    ap.add_argument("--opts", default="", help="semicolon list of option settings to run one after the other, e.g. ';attn_dkdv_kt=4;attn_dkdv_kt=4,attn_dq_qw=4'")
     ap.add_argument("--errors", action="store_true", help="also print rel-L2 of o / dq / dk / dv against fp32 SDPA (small B)")
     args = ap.parse_args()
     dev = "cuda"
@@ -29,10 +30,16 @@ def main():
     load_library().vj_attn_set_variant(args.fwd_qt)
     from jepa_amd.hip.lib import get_option, set_option
     sms = [int(v) for v in args.sm.split(",") if v.strip()] or [get_option("attn_softmax")]
+    settings = args.opts.split(";") if args.opts else [""]
     for sm in sms:
         set_option("attn_softmax", sm)
-        print(f"--- attn_softmax = {sm}", flush=True)
-        run_shapes(args, dev)
+        for st in settings:
+            kv = [x.partition("=") for x in st.split(",") if x.strip()]
+            olds = [(k.strip(), set_option(k.strip(), int(v))) for k, _, v in kv]
+            print(f"--- attn_softmax = {sm} {st}", flush=True)
+            run_shapes(args, dev)
+            for k, old in olds:
+                set_option(k, old)
 
 
 def errors(ops, B, S, H, hd):
