@@ -369,6 +369,9 @@ int vj_probe_copy(const void* src, void* dst, int64_t bytes, vj_stream_t stream)
 /* LDS read throughput of a CU, 8 waves x iters x 8 back-to-back reads: mode 0 ds_read_b128, 1 ds_read_b64_tr_b16 (the TN
  * GEMM's fragment addressing), 2 ds_read_b64; out[wg*8 + wave] = clock64 cycles (100 MHz timer ticks on gfx9) */
 int vj_probe_lds_bw(long long* out, int mode, int iters, int n_wgs, vj_stream_t stream);
+/* one wave idling for `ticks` periods of the 100 MHz timer: two of them on two streams take one spin time iff the streams are
+ * mapped to different hardware queues (used once per process to pick independent side / update / communication streams) */
+int vj_probe_spin(int64_t ticks, vj_stream_t stream);
 
 #ifdef __cplusplus
 }

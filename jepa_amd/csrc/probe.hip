@@ -93,3 +93,24 @@ extern "C" int vj_probe_lds_bw(long long* out, int mode, int iters, int n_wgs, h
   VJ_LAUNCH_CHECK("vj_probe_lds_bw");
   return 0;
 }
+
+// One wave that does nothing for `ticks` periods of the constant 100 MHz timer.  Two of them launched on two streams finish in one
+// spin time when the streams run concurrently and in two when they are serialised -- i.e. when the runtime mapped both streams
+// to the SAME hardware queue (ROCclr hands its GPU_MAX_HW_QUEUES queues to streams round-robin).  The engine uses it once per
+// process to choose side / update / communication streams that are independent of each other (engine/layers.py independent_stream):
+// a side stream that shares the main stream's queue turns the two-stream step into a serial one (+19 % measured, round 5).
+__global__ void probe_spin_kernel(long long ticks, long long* sink) {
+  const long long t0 = wall_clock64();
+  long long t = t0;
+  while (t - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    t = wall_clock64();
+  }
+  if (sink != nullptr && threadIdx.x == 0) *sink = t - t0;
+}
+extern "C" int vj_probe_spin(int64_t ticks, hipStream_t stream) {
+  VJ_CHECK_ARG(ticks >= 0 && ticks <= 100000000, "vj_probe_spin: ticks (100 MHz) outside [0, 1e8]");
+  hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, stream, (long long)ticks, (long long*)nullptr);
+  VJ_LAUNCH_CHECK("vj_probe_spin");
+  return 0;
+}

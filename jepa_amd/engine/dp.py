@@ -78,7 +78,12 @@ class GradReducer:
         self._ev_next = 0           # ordering events are pooled: one per bucket position, re-recorded every step
         self._producer = producer_stream
         if self.arena.G.is_cuda and self.overlap and self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream(device=self.arena.G.device)
+            # a communication stream that shares a hardware queue with neither compute stream: on a shared queue the collectives
+            # and the backward serialise (engine/layers.py independent_stream)
+            from .layers import independent_stream, side_stream
+            dev = self.arena.G.device
+            with torch.cuda.device(dev):
+                self.comm_stream = independent_stream(dev, [torch.cuda.current_stream(dev), side_stream(dev).stream])
 
     def _reduce(self, lo, hi, producer=None):
         g = self.arena.G[lo:hi]

@@ -34,7 +34,8 @@ class SideStream:
 
     def __init__(self, device):
         import os
-        self.stream = torch.cuda.Stream(device=device)
+        with torch.cuda.device(device):
+            self.stream = independent_stream(device, [torch.cuda.current_stream(device)])
         self.enabled = os.environ.get("VJ_NO_OVERLAP", "0") != "1"   # serial mode for per-kernel profiling
 
     def fork(self, *tensors):
@@ -65,6 +66,51 @@ def low_priority_stream(device):
         return torch.cuda.ExternalStream(h.value, device=dev)
     except (OSError, AttributeError):
         return torch.cuda.Stream(device=dev)
+
+
+_INDEP_LOG = []   # (candidate index, [concurrent with others[i]]) of every independent_stream() call: diagnostics / tests
+
+
+def streams_concurrent(a, b, spin_us=300.0):
+    """True when a kernel on stream `a` and one on stream `b` run at the same time (different hardware queues): two idle
+    one-wave kernels of `spin_us` each (vj_probe_spin), wall-clock around both.  Synchronises the device."""
+    import time
+    from ..hip.lib import check, load_library
+    lib = load_library()
+    ticks = int(spin_us * 100)
+    best = None
+    for _ in range(2):                       # the first pass also pays one-time costs (code load, queue creation)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        check(lib.vj_probe_spin(ticks, a.cuda_stream), "vj_probe_spin")
+        check(lib.vj_probe_spin(ticks, b.cuda_stream), "vj_probe_spin")
+        a.synchronize()
+        b.synchronize()
+        dt = (time.perf_counter() - t0) * 1e6
+        best = dt if best is None else min(best, dt)
+    return best < 1.6 * spin_us
+
+
+def independent_stream(device, others, make=None, tries=16):
+    """A stream that shares a hardware queue with none of `others` (torch streams).  ROCclr maps streams onto GPU_MAX_HW_QUEUES
+    hardware queues round-robin, and torch hands out its 32 pooled streams round-robin, so the n-th stream a process creates may
+    land on the queue of the main or the side stream -- kernels of the two then serialise (measured: 72 -> 86 ms per step when the
+    deferred update's stream aliased a forward stream, round 5; the same signature as the unexplained vj_comm_* slowdown of round 4).
+    Candidates come from `make()` (default: torch.cuda.Stream) and are tested with streams_concurrent; the last one is returned
+    with a warning if none is independent (GPU_MAX_HW_QUEUES too small)."""
+    dev = torch.device(device)
+    make = make or (lambda: torch.cuda.Stream(device=dev))
+    cand = None
+    for i in range(tries):
+        cand = make()
+        ok = [streams_concurrent(cand, o) for o in others]
+        _INDEP_LOG.append((i, ok))
+        if all(ok):
+            return cand
+    import warnings
+    warnings.warn("jepa_amd: no stream independent of the existing ones was found (GPU_MAX_HW_QUEUES too small?); "
+                  "streams will serialise on a shared hardware queue")
+    return cand
 
 
 _SIDE = {}

@@ -193,7 +193,7 @@ class Trainer:
         # same elements: results are bit-identical.  Off by default because anything that reads parameters with plain torch
         # operators right after train_step must then call sync_update() first (everything inside this package does).
         self.overlap_update = bool(overlap_update)
-        self._upd_stream = None     # created on first use (the flag may be flipped between steps: tools/abab.py)
+        self._upd_stream = self._make_update_stream() if self.overlap_update else None
         self._gates = None          # {'enc': [(first_block, event)], 'pred': [(0, event)], 'done': event} of the pending update
         self._plan = self._update_plan()
 
@@ -315,6 +315,15 @@ class Trainer:
     def opt_step(self, v):
         self._step_dev.fill_(float(v))
 
+    def _make_update_stream(self):
+        """A stream for the deferred update that shares a hardware queue with neither the main nor the side stream (a shared
+        queue serialises the two: engine/layers.py independent_stream)."""
+        from .layers import independent_stream
+        with torch.cuda.device(self.device):
+            others = [torch.cuda.current_stream(self.device), side_stream(self.device).stream]
+            make = (lambda: low_priority_stream(self.device)) if _UPD_LOW_PRIO else None
+            return independent_stream(self.device, others, make=make)
+
     def _gate(self, which):
         return None if self._gates is None else self._gates[which]
 
@@ -398,8 +407,8 @@ class Trainer:
             main = torch.cuda.current_stream()
             ready = torch.cuda.Event()
             ready.record(main)          # gradients, norms and the step count are final
-            if self._upd_stream is None:
-                self._upd_stream = (low_priority_stream(self.device) if _UPD_LOW_PRIO else torch.cuda.Stream(device=self.device))
+            if self._upd_stream is None:   # (normally created by the constructor; here after the flag was flipped between steps)
+                self._upd_stream = self._make_update_stream()
             upd = self._upd_stream
             upd.wait_event(ready)
             gates = {"enc": [], "pred": []}

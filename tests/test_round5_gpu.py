@@ -309,3 +309,17 @@ def test_attention_backward_with_four_tiles_per_wave_is_bit_identical(ops, B, S,
         for a, b in ((cq, cq0), (ckv, ckv0)):
             sa, sb = a.sum(0).double(), b.sum(0).double()
             assert float((sa - sb).norm() / (sb.norm() + 1e-30)) < 1e-5, (kt, qw)
+
+
+# ------------------------------------------------------------------------------------------ independent streams
+def test_independent_stream_picker():
+    """engine.layers.independent_stream returns a stream whose kernels run concurrently with those of the main and of the side
+    stream (vj_probe_spin on both, wall clock); a stream is never 'concurrent' with itself."""
+    from jepa_amd.engine import layers
+    main_s = torch.cuda.current_stream()
+    side = layers.side_stream(torch.device(DEV)).stream
+    assert layers.streams_concurrent(main_s, side)
+    assert not layers.streams_concurrent(side, side)
+    for _ in range(3):
+        s = layers.independent_stream(torch.device(DEV), [main_s, side])
+        assert layers.streams_concurrent(s, main_s) and layers.streams_concurrent(s, side)
