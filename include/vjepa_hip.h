@@ -301,6 +301,31 @@ int64_t vj_blocks_fwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads, 
 int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M, int64_t D,
                   int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save, int gemm_flags, void* ws,
                   int64_t ws_bytes, vj_stream_t stream);
+/* The same trunk for blocks that never run backward (the EMA target encoder of train.py:419-429, frozen-encoder inference) with both
+ * LayerNorms of every block FOLDED into the Linear that consumes them (modules.py:115,119 -> 63 / 31): a statistics pass reads the
+ * residual stream (vj_ln_rowstats), the qkv / fc1 GEMM reads it too and applies rstd_m * (acc - mean_m * c_n) + b'_n in its epilogue
+ * (vj_gemm_bf16_nt_lnfold) -- the LayerNorm output is never written or re-read.  folds[i]: block i's folded weights, prepared by
+ * vj_ln_fold_weights from the fp32 weights once per optimizer step.  Workspace: vj_blocks_fwd_ws_bytes(..., save = 0). */
+typedef struct vj_lnfold {
+  const void* w_qkv;    /* bf16 [3D, D] = bf16(W_qkv * diag(norm1.weight)) */
+  const float* c_qkv;   /* [3D]  row sums of w_qkv */
+  const float* b_qkv;   /* [3D]  qkv.bias + W_qkv norm1.bias */
+  const void* w_fc1;    /* bf16 [Dh, D] = bf16(W_fc1 * diag(norm2.weight)) */
+  const float* c_fc1;   /* [Dh] */
+  const float* b_fc1;   /* [Dh]  fc1.bias + W_fc1 norm2.bias */
+} vj_lnfold_t;
+int vj_blocks_fwd_lnfold(const vj_block_t* blocks, const vj_lnfold_t* folds, int64_t n_blocks, const void* x_in, void* x_out,
+                         int64_t M, int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int gemm_flags,
+                         void* ws, int64_t ws_bytes, vj_stream_t stream);
+/* the pieces (also usable alone): rowstats[m] = {rstd_m, -mean_m * rstd_m} of bf16 rows (fp32, two passes in registers, biased
+ * variance + eps: nn.LayerNorm's statistics); folded weights Wf = bf16(W diag(gamma)), cvec[n] = sum_k Wf[n,k], bf = b + W beta;
+ * C = LayerNorm(X) W^T + b from the raw rows X (epilogue 0 bf16, 1 GELU, 4 bf16 with the first N/3 columns times alpha) */
+int vj_ln_rowstats(const void* x_bf16, float* rowstats, int64_t rows, int64_t D, float eps, vj_stream_t stream);
+int vj_ln_fold_weights(const float* W, const float* b, const float* gamma, const float* beta, void* Wf_bf16, float* cvec, float* bf,
+                       int64_t N, int64_t K, vj_stream_t stream);
+int vj_gemm_bf16_nt_lnfold(const void* X, int64_t ldx, const void* Wf, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                           int64_t K, const float* bias_f, const float* rowstats, const float* colsum_w, int epilogue, float alpha,
+                           int flags, vj_stream_t stream);
 int64_t vj_blocks_bwd_ws_bytes(int64_t M, int64_t D, int64_t Dh, int64_t heads);
 /* dx_out [M,D] bf16 = d loss / d x_in given dout = d loss / d x_out; parameter gradients are written as
  * alpha * grad + beta_acc * old into the fp32 views of `blocks` (beta_acc = 1 accumulates micro-batches).

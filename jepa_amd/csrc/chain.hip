@@ -246,7 +246,7 @@ static int gemm(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
 }
 
 struct FwdLayout {
-  int64_t x, y1, qkv, o, x1, y2, u, g, mean1, rstd1, mean2, rstd2, lse, total;
+  int64_t x, y1, qkv, o, x1, y2, u, g, mean1, rstd1, mean2, rstd2, lse, rs, total;
   int64_t gap[16];   // option ws_guard: offsets of the 256-byte gaps behind the members
   int n_gap;
 };
@@ -277,6 +277,7 @@ static FwdLayout fwd_layout(int64_t M, int64_t D, int64_t Dh, int64_t H) {
   L.mean2 = take(M * 4);
   L.rstd2 = take(M * 4);
   L.lse = take(H * M * 4);
+  L.rs = take(M * 8);   // {rstd, -mean * rstd} per row: the LayerNorm folded into the consuming GEMM (vj_blocks_fwd_lnfold)
   L.total = off;
   return L;
 }
@@ -310,9 +311,14 @@ static int check_segs(const vj_seg_t* segs, int64_t n_segs, int64_t M, const cha
 }
 
 // ---------------------------------------------------------------------------------------------------- forward
-extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M,
-                             int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save,
-                             int gemm_flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+int vj_ln_rowstats(const void* x_bf16, float* rowstats, int64_t rows, int64_t D, float eps, hipStream_t stream);   // norm_loss.hip
+int vj_gemm_bf16_nt_lnfold(const void* X, int64_t ldx, const void* Wf, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                           int64_t K, const float* bias_f, const float* rowstats, const float* colsum_w, int epilogue, float alpha,
+                           int flags, hipStream_t stream);   // gemm.hip
+
+static int blocks_fwd_impl(const vj_block_t* blocks, const vj_lnfold_t* folds, int64_t n_blocks, const void* x_in, void* x_out, int64_t M,
+                           int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save,
+                           int gemm_flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
   // gemm_flags: low 16 bits = kernel selection of vj_gemm_bf16_nt (0: option gemm_fwd_flags); bits 16-23 = first block the
   // selection applies to (earlier blocks take the automatic choice) -- the EMA target encoder's late blocks run after the
   // context branch has left the GPU, where the two-workgroups-per-CU kernel (0x100) is the faster one
@@ -353,6 +359,14 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
     float* rstd1 = save ? (float*)(w + L.rstd1) : nullptr;
     float* mean2 = save ? (float*)(w + L.mean2) : nullptr;
     float* rstd2 = save ? (float*)(w + L.rstd2) : nullptr;
+    const vj_lnfold_t* fo = folds ? folds + li : nullptr;
+    if (fo) {   // LayerNorm folded into the qkv projection: a statistics pass over x (read only), the GEMM reads x itself
+      float* rs = (float*)(w + L.rs);
+      CH(vj_ln_rowstats(x, rs, M, D, ln_eps, stream));
+      ProfScope ps(stream, 0, 2.0 * M * 3 * D * D, M, 3 * D, D, 0);
+      CH(vj_gemm_bf16_nt_lnfold(x, D, fo->w_qkv, D, w + L.qkv, 3 * D, M, 3 * D, D, fo->b_qkv, rs, fo->c_qkv, qpre ? 4 : 0,
+                                qpre ? scale * 1.4426950408889634f : 1.0f, fwd_flags, stream));
+    } else {
     CH(vj_layernorm_fwd(x, b.norm1.g, b.norm1.b, w + L.y1, mean1, rstd1, M, D, ln_eps, stream));
     if (qpre) {   // option attn_softmax = 2: the q third carries scale * log2(e), applied before the bf16 rounding (epilogue 4)
       ProfScope ps(stream, 0, 2.0 * M * 3 * D * D, M, 3 * D, D, 0);
@@ -360,6 +374,7 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
                          scale * 1.4426950408889634f, 0.0f, fwd_flags, stream));
     } else {
       CH(gemm(w + L.y1, D, b.qkv.w, D, w + L.qkv, 3 * D, M, 3 * D, D, b.qkv.b, nullptr, 0, nullptr, nullptr, 0, 0, stream, fwd_flags));
+    }
     }
     if (merge_segs) {   // all segments (masks) in ONE launch: the short one's workgroups fill the long one's tail
       double fl = 0;
@@ -381,13 +396,40 @@ extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const v
       }
     }
     CH(gemm(w + L.o, D, b.proj.w, D, w + L.x1, D, M, D, D, b.proj.b, x, D, nullptr, nullptr, 0, 0, stream, fwd_flags));
+    if (fo) {   // LayerNorm folded into fc1 (GELU epilogue; no saved derivative: these blocks never run backward)
+      float* rs = (float*)(w + L.rs);
+      CH(vj_ln_rowstats(w + L.x1, rs, M, D, ln_eps, stream));
+      ProfScope ps(stream, 0, 2.0 * M * Dh * D, M, Dh, D, 1);
+      CH(vj_gemm_bf16_nt_lnfold(w + L.x1, D, fo->w_fc1, D, w + L.g, Dh, M, Dh, D, fo->b_fc1, rs, fo->c_fc1, 1, 1.0f, fwd_flags, stream));
+    } else {
     CH(vj_layernorm_fwd(w + L.x1, b.norm2.g, b.norm2.b, w + L.y2, mean2, rstd2, M, D, ln_eps, stream));
     CH(gemm(w + L.y2, D, b.fc1.w, D, w + L.g, Dh, M, Dh, D, b.fc1.b, nullptr, 0, nullptr, save ? w + L.u : nullptr, Dh,
             1, stream, fwd_flags));
+    }
     CH(gemm(w + L.g, Dh, b.fc2.w, Dh, x2, D, M, D, Dh, b.fc2.b, w + L.x1, D, nullptr, nullptr, 0, 0, stream, fwd_flags));
     x = x2;
   }
   return 0;
+}
+
+extern "C" int vj_blocks_fwd(const vj_block_t* blocks, int64_t n_blocks, const void* x_in, void* x_out, int64_t M,
+                             int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps, int save,
+                             int gemm_flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  return blocks_fwd_impl(blocks, nullptr, n_blocks, x_in, x_out, M, D, heads, segs, n_segs, ln_eps, save, gemm_flags, ws, ws_bytes, stream);
+}
+
+// The same trunk with both LayerNorms of every block folded into the Linear that consumes them (vj_gemm_bf16_nt_lnfold): for
+// blocks that never run backward (save must be 0) -- the EMA target encoder, frozen-encoder inference.  folds[i] holds block
+// i's folded qkv / fc1 weights (vj_ln_fold_weights); the blocks' own norm / qkv / fc1 weights are not read.  Workspace as
+// vj_blocks_fwd_ws_bytes(..., save = 0).
+extern "C" int vj_blocks_fwd_lnfold(const vj_block_t* blocks, const vj_lnfold_t* folds, int64_t n_blocks, const void* x_in, void* x_out,
+                                    int64_t M, int64_t D, int64_t heads, const vj_seg_t* segs, int64_t n_segs, float ln_eps,
+                                    int gemm_flags, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  VJ_CHECK_ARG(folds != nullptr, "vj_blocks_fwd_lnfold: no folded weights");
+  for (int64_t i = 0; i < n_blocks; i++)
+    VJ_CHECK_ARG(folds[i].w_qkv && folds[i].c_qkv && folds[i].b_qkv && folds[i].w_fc1 && folds[i].c_fc1 && folds[i].b_fc1,
+                 "vj_blocks_fwd_lnfold: block %ld lacks folded weights", (long)i);
+  return blocks_fwd_impl(blocks, folds, n_blocks, x_in, x_out, M, D, heads, segs, n_segs, ln_eps, 0, gemm_flags, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------- backward

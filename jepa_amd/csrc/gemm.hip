@@ -272,6 +272,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
   int cfg = (flags >> 4) & 3;
   int pipe = (flags >> 6) & 3;
   const bool is_wgrad = (EPI == EPI_F32 && ws != nullptr);
+  if (a.lnf_rs != nullptr) flags &= ~0x300;   // the 4-wave kernels carry no folded-LayerNorm epilogue
   // bit 9 (round 5): the PERSISTENT form of the 4-wave kernel (two workgroups per CU walking tile lists); bit-identical outputs
   if ((flags & 0x200) && !is_wgrad && !reg_staged) {
     const int rc = vj_gemm_launch_4wp(a, EPI, stream);
@@ -291,7 +292,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     // 87.0 ms (8-phase) vs 90.0 ms (4-wave) per step, for every selection policy tried.  So it is opt-in: flags bit 8 or
     // VJ_GEMM_4W=1 (all forward / dgrad GEMMs), meant for single-stream use (inference, profiling).
     const int64_t t4w = cdiv64(a.M, 256) * cdiv64(a.N, 128);
-    const int use_4w = vj_opt(VJ_OPT_GEMM_4W);
+    const int use_4w = a.lnf_rs != nullptr ? 0 : vj_opt(VJ_OPT_GEMM_4W);
     if (use_4w == 1 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 64)
       return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
     // 2: only where a 256-wide tile wastes a third of its columns (N = 384: the predictor's proj / fc2 / dgrad outputs)
@@ -319,7 +320,9 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
       const int rc = vj_gemm_launch_8phase_persist(a, EPI, stream);
       if (rc != -100) return rc;
     }
-    return vj_gemm_launch_8phase(a, EPI, ws, ws_bytes, stream);
+    if (a.lnf_rs == nullptr) return vj_gemm_launch_8phase(a, EPI, ws, ws_bytes, stream);
+    pipe = 1;   // folded LayerNorm: only the persistent kernel and the generic kernels below carry that epilogue
+    if (cfg == 1 && a.M >= 256 && a.N >= 256) cfg = 2;
   }
   if (pipe == 3) pipe = 1;
   if (reg_staged) {
@@ -338,7 +341,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
 static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                       int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
                       void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags, void* ws,
-                      int64_t ws_bytes, hipStream_t stream) {
+                      int64_t ws_bytes, hipStream_t stream, const float* lnf_rs = nullptr, const float* lnf_c = nullptr) {
   VJ_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "vj_gemm_bf16_nt: negative dim");
   if (M == 0 || N == 0) return 0;
   VJ_CHECK_ARG(K > 0 && K % 32 == 0, "vj_gemm_bf16_nt: K=%ld must be a positive multiple of 32 (pad the operands)", (long)K);
@@ -369,6 +372,8 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.colpart = nullptr;
   a.gelu_lp = vj_opt(VJ_OPT_GELU_POLY);
   a.raster = 0;
+  a.lnf_rs = lnf_rs;
+  a.lnf_c = lnf_c;
   a.qscale = qscale;
   a.qcols = qscale != 0.f ? N / 3 : 0;
   switch (epilogue) {
@@ -385,6 +390,23 @@ extern "C" int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_
                                float beta, int flags, hipStream_t stream) {
   return gemm_entry(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, aux_in, aux_out, ldaux, epilogue, alpha, beta,
                     flags, nullptr, 0, stream);
+}
+
+// LayerNorm folded into the Linear that consumes it (round 5): C = LayerNorm(X) W^T + b computed from the RAW rows X as
+//   C[m,n] = rstd_m * (sum_k X[m,k] Wf[n,k] - mean_m * c[n]) + bf[n],   Wf = bf16(W diag(gamma)), c[n] = sum_k Wf[n,k], bf = b + W beta
+// (vj_ln_fold_weights prepares Wf / c / bf, vj_ln_rowstats the rows' {rstd, -mean * rstd}): the LayerNorm output is never written or
+// re-read, and the activation is rounded to bf16 once less than on the unfused path.  epilogue: 0 (bf16), 1 (GELU, no saved
+// derivative) or 4 (bf16 with the first N/3 columns times alpha: the q third of a qkv projection).  Replaces: norm1 -> attn.qkv and
+// norm2 -> mlp.fc1 of a Block whose backward never runs (the EMA target encoder, frozen-encoder inference): modules.py:115,119.
+extern "C" int vj_gemm_bf16_nt_lnfold(const void* X, int64_t ldx, const void* Wf, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                      int64_t N, int64_t K, const float* bias_f, const float* rowstats, const float* colsum_w,
+                                      int epilogue, float alpha, int flags, hipStream_t stream) {
+  VJ_CHECK_ARG(bias_f != nullptr && rowstats != nullptr && colsum_w != nullptr, "vj_gemm_bf16_nt_lnfold: bias_f / rowstats / colsum_w must be given");
+  VJ_CHECK_ARG(epilogue == EPI_BF16 || epilogue == EPI_GELU || epilogue == EPI_QKV_API, "vj_gemm_bf16_nt_lnfold: epilogue %d (0, 1 or 4)", epilogue);
+  VJ_CHECK_ARG(((uintptr_t)rowstats % 8 == 0) && ((uintptr_t)colsum_w % 16 == 0) && ((uintptr_t)bias_f % 16 == 0),
+               "vj_gemm_bf16_nt_lnfold: rowstats / colsum_w / bias_f misaligned");
+  return gemm_entry(X, ldx, Wf, ldw, C, ldc, M, N, K, bias_f, nullptr, 0, nullptr, nullptr, 0, epilogue, alpha, 0.0f, flags, nullptr, 0,
+                    stream, rowstats, colsum_w);
 }
 
 // fc2 dgrad with the bias gradient of fc1 fused: C = (A B^T) * aux_in (EPI_DGELU) and, when the persistent 256x256 kernel
@@ -420,6 +442,8 @@ extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const vo
     a.colpart = colpart;
     a.gelu_lp = 0;
     a.raster = 0;
+    a.lnf_rs = nullptr;
+    a.lnf_c = nullptr;
     const int rc = vj_gemm_launch_8phase_persist(a, EPI_DGELU, stream);
     if (rc != -100) {
       *fused = (rc == 0);

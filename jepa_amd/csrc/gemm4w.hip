@@ -295,10 +295,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_4w_kernel(GemmArgs p) {
   }
   const int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int efrow = elane & 15, efg = elane >> 4;
-  if (!(p.dbg & 2) && gemm_epilogue_try_staged<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
-                                                    smem + wave_u * 16384))
+  if (!(p.dbg & 2) && gemm_epilogue_try_staged<EPI, 8, false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+                                                              smem + wave_u * 16384))
     return;
-  gemm_epilogue<EPI, 8, 4, /*INTERIOR_VARIANT=*/(EPI == EPI_F32)>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, slice);
+  gemm_epilogue<EPI, 8, 4, /*INTERIOR_VARIANT=*/(EPI == EPI_F32), false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, slice);
 }
 
 // ---- persistent form (round 5, flags bit 9 / option gemm_4w = 3: the experiment VERDICT r4 item 1 asks for) -----------------
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_4wp_kernel(GemmArgs p) {
     int elane;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
     const int efrow = elane & 15, efg = elane >> 4;
-    if (!gemm_epilogue_try_staged<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane, smem + wave_u * 16384))
-      gemm_epilogue<EPI, 8, 4, false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, 0);
+    if (!gemm_epilogue_try_staged<EPI, 8, false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane, smem + wave_u * 16384))
+      gemm_epilogue<EPI, 8, 4, false, false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, 0);
     bar4();   // every wave has read its staging region back: the next tile's prologue may overwrite the ring
   }
 }
@@ -432,7 +432,7 @@ int vj_gemm_launch_4wp(const GemmArgs& a, int epilogue, hipStream_t stream) {
       return -100;
     g_4wp_cus = n;
   }
-  if (epilogue == EPI_F32 || a.M < W4_BM || a.N < W4_BN || a.K % W4_BK != 0 || a.K < 3 * W4_BK) return -100;
+  if (epilogue == EPI_F32 || a.M < W4_BM || a.N < W4_BN || a.K % W4_BK != 0 || a.K < 3 * W4_BK || a.lnf_rs != nullptr) return -100;
   if (a.lda >= (1 << 23) || a.ldb >= (1 << 23) || a.colpart != nullptr) return -100;
   auto overlaps = [&](const void* q, int64_t ld) {   // shifted edge tiles rewrite their neighbours' outputs: inputs must not alias C
     if (q == nullptr) return false;

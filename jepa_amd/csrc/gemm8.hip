@@ -272,10 +272,10 @@ __device__ __forceinline__ void gemm8_body(const GemmArgs& p, char* smem, int tm
   // The lane id is re-derived here (mbcnt) so that nothing epilogue-only stays live across the K loop (256 VGPRs).
   const int elane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int efrow = elane & 15, efg = elane >> 4;
-  if (!(p.dbg & 2) && gemm_epilogue_try_staged<EPI>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+  if (!(p.dbg & 2) && gemm_epilogue_try_staged<EPI, 8, false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
                                                     smem + wave_u * 16384))
     return;
-  gemm_epilogue<EPI, 8, 4, /*INTERIOR_VARIANT=*/(EPI == EPI_F32)>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, slice);
+  gemm_epilogue<EPI, 8, 4, /*INTERIOR_VARIANT=*/(EPI == EPI_F32), false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, slice);
 }
 
 template <int EPI>

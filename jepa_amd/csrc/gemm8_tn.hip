@@ -159,6 +159,8 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
   GemmArgs p;
   p.colpart = nullptr;
   p.gelu_lp = 0;
+  p.lnf_rs = nullptr;
+  p.lnf_c = nullptr;
   p.raster = 0;
   p.qscale = 0.f;
   p.qcols = 0;
@@ -392,6 +394,8 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
   GemmArgs b;
   b.colpart = nullptr;
   b.gelu_lp = 0;
+  b.lnf_rs = nullptr;
+  b.lnf_c = nullptr;
   b.raster = 0;
   b.qscale = 0.f;
   b.qcols = 0;

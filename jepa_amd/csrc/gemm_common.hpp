@@ -27,6 +27,11 @@ struct GemmArgs {
                        // (row slot = 2 * row tile + wave row): the bias gradient of the Linear whose dY this GEMM produces
   int raster;          // persistent kernel: tile order (tile_of_raster; 0 = the default 8-row groups)
   int gelu_lp;         // EPI_GELU: != 0 -> Phi(-|x|) = exp2(degree-6 polynomial) (common.hpp, option gelu_poly); 0 -> A-S 7.1.26
+  // LayerNorm folded into this GEMM (round 5; bf16 / GELU epilogues without residual or saved derivative): A holds the RAW rows x
+  // (not LayerNorm(x)), B = bf16(W * diag(gamma)), bias = b + W beta, lnf_c[n] = sum_k B[n,k] and lnf_rs[m] = {rstd_m, -mean_m * rstd_m}:
+  //   out[m,n] = rstd_m * (acc[m,n] - mean_m * c[n]) + bias[n]  =  LayerNorm(x)[m,:] . W[n,:] + b[n]      (vj_gemm_bf16_nt_lnfold)
+  const float* lnf_rs;   // [M][2] fp32, nullable (null: plain epilogue)
+  const float* lnf_c;    // [N] fp32
 };
 
 
@@ -40,10 +45,11 @@ struct GemmArgs {
 // nullable operands are resolved once by the caller-side variant switch (HAS_OPT), the bias is complete before the
 // first row (one explicit wait), and the row operands (residual / saved pre-activation) are fetched one row-block ahead
 // so that a row's stores stay in flight while the next row is computed.
-template <int EPI, int FM, int FN, bool HAS_OPT, bool EDGE, bool BETA = false, bool QS = false, bool LP = false>
+template <int EPI, int FM, int FN, bool HAS_OPT, bool EDGE, bool BETA = false, bool QS = false, bool LP = false, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int64_t m_base,
                                                    int64_t n_base, int frow, int fg, int slice) {
   static_assert(!QS || (EPI == EPI_BF16 && !HAS_OPT), "column scale: the qkv projection (bf16 output, no residual)");
+  static_assert(!LNF || ((EPI == EPI_BF16 || EPI == EPI_GELU) && !HAS_OPT), "LayerNorm fold: bf16 / GELU epilogue, no residual, no saved derivative");
   const int64_t ncol0 = n_base + fg * 4;   // this lane's first column; tile j adds j*16
   f32x2_t qs2[QS ? FN : 1];
   if constexpr (QS) {
@@ -69,6 +75,11 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 #pragma unroll
       for (int j = 0; j < FN; j++) bias4[j] = *(const float4*)(p.bias + ncl[j]);
     }
+  }
+  float4 lc4[LNF ? FN : 1];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int j = 0; j < FN; j++) lc4[j] = *(const float4*)(p.lnf_c + ncl[j]);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), visible to the compiler: nothing older than the epilogue is pending
 
@@ -116,10 +127,20 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
       for (int j = 0; j < FN; j++) dst[j] = *(const u32x2_t*)(base + ncl[j]);
     };
     if constexpr (HAS_OPND) load_row(0, opnd[0]);
+    f32x2_t lrs[2];   // LNF: {rstd, -mean * rstd} of this lane's row, fetched one row block ahead like the row operands
+    auto load_rs = [&](int i) {
+      int64_t m = m_base + i * 16 + frow;
+      if constexpr (EDGE) m = m < p.M ? m : p.M - 1;
+      return *(const f32x2_t*)(p.lnf_rs + 2 * m);
+    };
+    if constexpr (LNF) lrs[0] = load_rs(0);
 #pragma unroll
     for (int i = 0; i < FM; i++) {
       if constexpr (HAS_OPND) {
         if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
+      }
+      if constexpr (LNF) {
+        if (i + 1 < FM) lrs[(i + 1) & 1] = load_rs(i + 1);
       }
       const int64_t m = m_base + i * 16 + frow;
       const bool mok = EDGE ? m < p.M : true;
@@ -128,8 +149,17 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
       bf16_t* auxo = (EPI == EPI_GELU && HAS_OPT) ? p.aux_out + mc * p.ldaux : nullptr;
 #pragma unroll
       for (int j = 0; j < FN; j++) {
-        f32x2_t v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
-        f32x2_t v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
+        f32x2_t v01, v23;
+        if constexpr (LNF) {   // rstd * acc + (-mean * rstd) * c[n] + b'[n]
+          const f32x2_t r2 = {lrs[i & 1][0], lrs[i & 1][0]}, s2 = {lrs[i & 1][1], lrs[i & 1][1]};
+          v01 = __builtin_elementwise_fma((f32x2_t){acc[i][j][0], acc[i][j][1]}, r2,
+                                          __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].x, lc4[j].y}, (f32x2_t){bias4[j].x, bias4[j].y}));
+          v23 = __builtin_elementwise_fma((f32x2_t){acc[i][j][2], acc[i][j][3]}, r2,
+                                          __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].z, lc4[j].w}, (f32x2_t){bias4[j].z, bias4[j].w}));
+        } else {
+          v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
+          v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
+        }
         if constexpr (QS) {
           v01 *= qs2[j];
           v23 *= qs2[j];
@@ -188,7 +218,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 // rows below `row_lo` -- the part of a SHIFTED edge tile that belongs to its neighbour -- are left out) and writes the 64
 // column sums to p.colpart[slot][n_base ..]: du = dY of fc1 is produced here, so fc1's bias gradient costs 64 packed FMAs + 64
 // DPP adds per wave tile instead of a second pass over du (colsum_bf16_kernel: 84 MB per ViT-L context block).
-template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false>
+template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage,
                                                      int64_t row_lo = 0, int slot = 0) {
@@ -211,6 +241,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
   if (p.bias) {
 #pragma unroll
     for (int j = 0; j < FN; j++) bias4[j] = *(const float4*)(p.bias + ncl[j]);
+  }
+  static_assert(!LNF || ((EPI == EPI_BF16 || EPI == EPI_GELU) && !HAS_OPT && !CSUM), "LayerNorm fold: bf16 / GELU epilogue, no residual, no saved derivative");
+  float4 lc4[LNF ? FN : 1];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int j = 0; j < FN; j++) lc4[j] = *(const float4*)(p.lnf_c + ncl[j]);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
 
@@ -272,6 +308,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
   }
   const int row_first = (int)(row_lo - m_base) - frow;   // CSUM: block i of this lane counts iff i * 16 >= row_first
   if constexpr (HAS_OPND) load_row(0, opnd[0]);
+  f32x2_t lrs[2];   // LNF: {rstd, -mean * rstd} of this lane's row, fetched one row block ahead like the row operands
+  auto load_rs = [&](int i) {
+    int64_t m = m_base + i * 16 + frow;
+    if constexpr (EDGE) m = m < p.M ? m : p.M - 1;
+    return *(const f32x2_t*)(p.lnf_rs + 2 * m);
+  };
+  if constexpr (LNF) lrs[0] = load_rs(0);
 #pragma unroll
   for (int ps = 0; ps < FM / RPP; ps++) {
 #pragma unroll
@@ -280,6 +323,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       if constexpr (HAS_OPND) {
         if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
       }
+      if constexpr (LNF) {
+        if (i + 1 < FM) lrs[(i + 1) & 1] = load_rs(i + 1);
+      }
       f32x2_t mk2 = {1.f, 1.f};
       if constexpr (CSUM) {
         const float mk = (i * 16 >= row_first) ? 1.f : 0.f;
@@ -287,8 +333,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       }
 #pragma unroll
       for (int j = 0; j < FN; j++) {
-        f32x2_t v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
-        f32x2_t v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
+        f32x2_t v01, v23;
+        if constexpr (LNF) {   // rstd * acc + (-mean * rstd) * c[n] + b'[n]
+          const f32x2_t r2 = {lrs[i & 1][0], lrs[i & 1][0]}, s2 = {lrs[i & 1][1], lrs[i & 1][1]};
+          v01 = __builtin_elementwise_fma((f32x2_t){acc[i][j][0], acc[i][j][1]}, r2,
+                                          __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].x, lc4[j].y}, (f32x2_t){bias4[j].x, bias4[j].y}));
+          v23 = __builtin_elementwise_fma((f32x2_t){acc[i][j][2], acc[i][j][3]}, r2,
+                                          __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].z, lc4[j].w}, (f32x2_t){bias4[j].z, bias4[j].w}));
+        } else {
+          v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
+          v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
+        }
         if constexpr (QS) {
           v01 *= qs2[j];
           v23 *= qs2[j];
@@ -362,7 +417,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
 
 // staged variant selector for the 8-phase kernel (wave tile 128 x 64); falls back to the direct form when the 16-byte
 // row-major stores cannot be used (N, ldc or the base pointers not 8-element aligned) and for fp32 outputs
-template <int EPI, int IPP = 8>
+// (ALLOW_LNF = false: kernels that are never launched with a folded LayerNorm leave those variants out -- the 4-wave kernels'
+//  scalar register budget is spent on their twelve wave-uniform DMA bases)
+template <int EPI, int IPP = 8, bool ALLOW_LNF = true>
 __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                          int64_t n_base, int frow, int fg, int lane, char* stage,
                                                          int64_t row_lo = 0, int slot = 0) {
@@ -380,6 +437,28 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     if constexpr (EPI == EPI_DGELU && IPP == 2) {   // persistent kernel (every tile interior): optional fused column sums
       if (p.colpart != nullptr && !edge) {
         gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot);
+        return true;
+      }
+    }
+    if constexpr (ALLOW_LNF && (EPI == EPI_BF16 || EPI == EPI_GELU)) {
+      if (p.lnf_rs != nullptr) {   // LayerNorm folded into this GEMM (workgroup-uniform; the launcher guarantees: no residual / aux_out)
+        if constexpr (EPI == EPI_BF16) {
+          if (p.qscale != 0.f && n_base < p.qcols) {
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          } else {
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          }
+        } else {
+          if (p.gelu_lp) {
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          } else {
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          }
+        }
         return true;
       }
     }
@@ -413,7 +492,7 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
   }
 }
 
-template <int EPI, int FM, int FN, bool INTERIOR_VARIANT = true>
+template <int EPI, int FM, int FN, bool INTERIOR_VARIANT = true, bool ALLOW_LNF = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[FM][FN], int64_t m_base,
                                               int64_t n_base, int frow, int fg, int slice) {
   bool opt;   // workgroup-uniform: resolved once, each variant is branch-free inside
@@ -424,6 +503,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
   // interior wave tiles (the vast majority) carry no predicates at all
   const bool edge =
       !INTERIOR_VARIANT || __builtin_amdgcn_readfirstlane((m_base + FM * 16 > p.M) || (n_base + FN * 16 > p.N));
+  if constexpr (ALLOW_LNF && (EPI == EPI_BF16 || EPI == EPI_GELU)) {
+    if (p.lnf_rs != nullptr) {   // LayerNorm folded into this GEMM (the launcher guarantees: no residual / aux_out); always the predicated form
+      if constexpr (EPI == EPI_BF16) {
+        if (p.qscale != 0.f && n_base < p.qcols) gemm_epilogue_impl<EPI, FM, FN, false, true, false, true, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+        else gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      } else {
+        if (p.gelu_lp) gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, true, true>(p, acc, m_base, n_base, frow, fg, slice);
+        else gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      }
+      return;
+    }
+  }
   if constexpr (EPI == EPI_BF16) {
     if (p.qscale != 0.f && n_base < p.qcols) {   // wave tiles that hold q columns only (the launcher guarantees: no residual)
       if (edge) gemm_epilogue_impl<EPI, FM, FN, false, true, false, true>(p, acc, m_base, n_base, frow, fg, slice);

@@ -126,6 +126,105 @@ extern "C" int vj_layernorm_fwd(const void* x_bf16, const float* gamma, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// LayerNorm folded into the consuming Linear (round 5; vj_gemm_bf16_nt_lnfold, gemm.hip): what is left of the LayerNorm pass.
+//   rowstats: rs[m] = {rstd_m, -mean_m * rstd_m} of the bf16 rows x -- the same two-pass fp32 statistics as layernorm_fwd_kernel
+//             (mean, then the variance of the centred values: no E[x^2] - mean^2 cancellation), but x is only READ: half the bytes
+//             of the LayerNorm pass, and the GEMM that consumed its output now reads x directly.
+//   fold_weights: Wf[n,:] = bf16(W[n,:] * gamma), c[n] = sum_k Wf[n,k] (of the ROUNDED values: the epilogue's acc - mean * c then
+//             cancels exactly what the matrix pipe accumulated), bf[n] = b[n] + sum_k W[n,k] beta[k].  One wave per output row;
+//             run once per optimizer step on the EMA target's fp32 weights.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_rowstats_kernel(const bf16_t* __restrict__ x, float* __restrict__ rs, int64_t rows, int D,
+                                                          float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  const float invD = 1.0f / (float)D;
+  for (int64_t r = wave; r < rows; r += nw) {
+    const bf16_t* xp = x + r * D;
+    float v[LN_MAX_CHUNKS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+        load8(xp + c, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[i][j];
+      }
+    }
+    const float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float d = v[i][j] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+    if (lane == 0) *(float2*)(rs + 2 * r) = make_float2(rstd, -mean * rstd);
+  }
+}
+
+extern "C" int vj_ln_rowstats(const void* x_bf16, float* rowstats, int64_t rows, int64_t D, float eps, hipStream_t stream) {
+  VJ_CHECK_ARG(D % 8 == 0 && D <= 512 * LN_MAX_CHUNKS, "vj_ln_rowstats: D=%ld unsupported (need D%%8==0, D<=%d)", (long)D, 512 * LN_MAX_CHUNKS);
+  VJ_CHECK_ARG(rowstats != nullptr && ((uintptr_t)rowstats % 8 == 0), "vj_ln_rowstats: rowstats null or misaligned");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(ln_rowstats_kernel, dim3(ln_grid(rows)), dim3(256), 0, stream, (const bf16_t*)x_bf16, rowstats, rows, (int)D, eps);
+  VJ_LAUNCH_CHECK("vj_ln_rowstats");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              bf16_t* __restrict__ Wf, float* __restrict__ cvec, float* __restrict__ bf,
+                                                              int64_t N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* wp = W + n * K;
+  bf16_t* op = Wf + n * K;
+  float sc = 0.f, sb = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {   // K % 4 == 0
+    const float4 w = *(const float4*)(wp + k);
+    const float4 g = *(const float4*)(gamma + k);
+    const float4 be = *(const float4*)(beta + k);
+    u32x2_t o;
+    o[0] = pack_bf2(w.x * g.x, w.y * g.y);
+    o[1] = pack_bf2(w.z * g.z, w.w * g.w);
+    *(u32x2_t*)(op + k) = o;
+    sc += (bf_lo(o[0]) + bf_hi(o[0])) + (bf_lo(o[1]) + bf_hi(o[1]));
+    sb += (w.x * be.x + w.y * be.y) + (w.z * be.z + w.w * be.w);
+  }
+  sc = wave_sum(sc);
+  sb = wave_sum(sb);
+  if (lane == 0) {
+    cvec[n] = sc;
+    bf[n] = (b ? b[n] : 0.f) + sb;
+  }
+}
+
+// W [N,K] fp32 (row-major, contiguous), b [N] fp32 or null, gamma / beta [K] fp32 -> Wf [N,K] bf16, cvec [N], bf [N]
+extern "C" int vj_ln_fold_weights(const float* W, const float* b, const float* gamma, const float* beta, void* Wf_bf16, float* cvec,
+                                  float* bf, int64_t N, int64_t K, hipStream_t stream) {
+  VJ_CHECK_ARG(W != nullptr && gamma != nullptr && beta != nullptr && Wf_bf16 != nullptr && cvec != nullptr && bf != nullptr,
+               "vj_ln_fold_weights: null pointer");
+  VJ_CHECK_ARG(K % 4 == 0 && K > 0 && N >= 0 && K < (1 << 30), "vj_ln_fold_weights: K=%ld must be a positive multiple of 4", (long)K);
+  VJ_CHECK_ARG((((uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0) && ((uintptr_t)Wf_bf16 % 8 == 0),
+               "vj_ln_fold_weights: W / gamma / beta must be 16-byte aligned, Wf 8-byte aligned");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((unsigned)cdiv64(N, 4)), dim3(256), 0, stream, W, b, gamma, beta, (bf16_t*)Wf_bf16,
+                     cvec, bf, N, (int)K);
+  VJ_LAUNCH_CHECK("vj_ln_fold_weights");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // layernorm_bwd: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres], g = dy*gamma
 // per-block partial dgamma/dbeta in fp32 -> part[blk][0:D]=dgamma, part[blk][D:2D]=dbeta
 // CS: also the column sums of the OUTPUT dx (fp32, before the bf16 rounding) -> part[blk][2D:3D].  In a transformer block

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from ..hip.lib import LAYER_CB, VjBlock, VjLinear, VjNorm, VjSeg, check, get_option, load_library
+from ..hip.lib import LAYER_CB, VjBlock, VjLinear, VjLnFold, VjNorm, VjSeg, check, get_option, load_library
 
 
 def _p(t):
@@ -35,6 +35,14 @@ def block_array(blocks):
     arr = (VjBlock * len(blocks))()
     for i, b in enumerate(blocks):
         arr[i] = VjBlock(_norm(b.norm1), _lin(b.qkv), _lin(b.proj), _norm(b.norm2), _lin(b.fc1), _lin(b.fc2))
+    return arr
+
+
+def fold_array(folds):
+    """ctypes array of vj_lnfold_t over a list of FoldW (stable buffers: refreshed in place)."""
+    arr = (VjLnFold * len(folds))()
+    for i, f in enumerate(folds):
+        arr[i] = VjLnFold(_p(f.w_qkv), _p(f.c_qkv), _p(f.b_qkv), _p(f.w_fc1), _p(f.c_fc1), _p(f.b_fc1))
     return arr
 
 
@@ -109,9 +117,22 @@ def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None, gemm_flags=0,
     st = torch.cuda.current_stream().cuda_stream if stream is None else stream
     qpre = get_option("attn_softmax") == 2 and D % 4 == 0   # what vj_blocks_fwd is about to do (chain.hip: (3 * D) % 12 == 0)
     cuts = sorted({b for b, _ in gates if 0 < b < n}) if gates else []
+    # folded LayerNorms (vj_blocks_fwd_lnfold): only for a trunk that keeps nothing for a backward
+    farr = None
+    if getattr(views, "folds", None) is not None and not save:
+        farr = getattr(views, "_cfolds", None)
+        if farr is None:
+            farr = views._cfolds = fold_array(views.folds)
+
+    def call(sub, fsub, nb, xin, xout, flags, ws_ptr, ws_left):
+        if fsub is not None:
+            check(lib.vj_blocks_fwd_lnfold(sub, fsub, nb, xin, xout, M, D, views.heads, sa, len(segs), ln_eps, flags, ws_ptr, ws_left,
+                                           st), "vj_blocks_fwd_lnfold")
+        else:
+            check(lib.vj_blocks_fwd(sub, nb, xin, xout, M, D, views.heads, sa, len(segs), ln_eps, int(save), flags, ws_ptr, ws_left,
+                                    st), "vj_blocks_fwd")
     if not cuts:
-        check(lib.vj_blocks_fwd(arr, n, x.data_ptr(), out.data_ptr(), M, D, views.heads, sa, len(segs), ln_eps, int(save),
-                                gemm_flags, ws.data_ptr(), ws.numel(), st), "vj_blocks_fwd")
+        call(arr, farr, n, x.data_ptr(), out.data_ptr(), gemm_flags, ws.data_ptr(), ws.numel())
         return out, (TrunkCtx(x, ws, M, D, segs, sa, qpre) if save else None)
     if stream is not None:
         raise ValueError("blocks_forward: gated ranges are enqueued on the current torch stream")
@@ -137,8 +158,8 @@ def blocks_forward(x, views, segs, save, tag, ln_eps, stream=None, gemm_flags=0,
         rel = max(0, sel_from - b0)                       # "first block the kernel selection applies to", relative to this call
         flags = 0 if (gemm_flags >> 16 and rel >= b1 - b0) else (gemm_flags & 0xffff) | (rel << 16)
         sub = ctypes.cast(ctypes.byref(arr, b0 * ctypes.sizeof(VjBlock)), ctypes.POINTER(VjBlock))
-        check(lib.vj_blocks_fwd(sub, b1 - b0, cur_in, out_ptr, M, D, views.heads, sa, len(segs), ln_eps, int(save), flags,
-                                ws_ptr, ws_left, st), "vj_blocks_fwd")
+        fsub = None if farr is None else ctypes.cast(ctypes.byref(farr, b0 * ctypes.sizeof(VjLnFold)), ctypes.POINTER(VjLnFold))
+        call(sub, fsub, b1 - b0, cur_in, out_ptr, flags, ws_ptr, ws_left)
         cur_in = out_ptr
     return out, (TrunkCtx(x, ws, M, D, segs, sa, qpre) if save else None)
 

@@ -160,16 +160,29 @@ def _f32_mul(a: float, b: float) -> float:
 
 
 # =============================================================================================== block
-def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
-    """x [M, D] bf16 -> x2 [M, D]; returns (x2, saved)."""
+def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool, fold=None):
+    """x [M, D] bf16 -> x2 [M, D]; returns (x2, saved).  fold (FoldW, only with save = False): both LayerNorms folded into the
+    GEMMs that consume them -- the kernels and their order are those of vj_blocks_fwd_lnfold (bit-identical results)."""
     D = x.shape[1]
     hd = D // heads
     scale = hd ** -0.5
-    y1, mean1, rstd1 = ops.layernorm_fwd(x, bw.norm1.g, bw.norm1.b, LN_EPS, save_stats=save)
-    if _q_prescaled(D):   # option attn_softmax = 2 (as vj_blocks_fwd): the q third of qkv carries scale * log2(e)
+    if fold is not None and save:
+        raise ValueError("block_forward: folded LayerNorms keep nothing for a backward")
+    y1 = mean1 = rstd1 = None
+    if fold is not None:
+        rs = ops.ln_rowstats(x, LN_EPS)
+        if _q_prescaled(D):
+            qkv = ops.gemm_nt_lnfold(x, fold.w_qkv, fold.b_qkv, rs, fold.c_qkv, epilogue=ops.EPI_QKV,
+                                     alpha=_f32_mul(scale, 1.4426950408889634))
+            scale = -scale
+        else:
+            qkv = ops.gemm_nt_lnfold(x, fold.w_qkv, fold.b_qkv, rs, fold.c_qkv)
+    elif _q_prescaled(D):   # option attn_softmax = 2 (as vj_blocks_fwd): the q third of qkv carries scale * log2(e)
+        y1, mean1, rstd1 = ops.layernorm_fwd(x, bw.norm1.g, bw.norm1.b, LN_EPS, save_stats=save)
         qkv = ops.gemm_nt(y1, bw.qkv.w, bias=bw.qkv.b, epilogue=ops.EPI_QKV, alpha=_f32_mul(scale, 1.4426950408889634))
         scale = -scale    # "q is pre-scaled" for the attention entry points
     else:
+        y1, mean1, rstd1 = ops.layernorm_fwd(x, bw.norm1.g, bw.norm1.b, LN_EPS, save_stats=save)
         qkv = ops.gemm_nt(y1, bw.qkv.w, bias=bw.qkv.b)
     o = torch.empty_like(x)
     lses = []
@@ -177,10 +190,14 @@ def block_forward(x, bw: BlockW, segs: List[Seg], heads: int, save: bool):
         _, lse = ops.attn_fwd(_rows(qkv, sg), sg.B, sg.S, heads, hd, scale, save_lse=save, out=_rows(o, sg))
         lses.append(lse)
     x1 = ops.gemm_nt(o, bw.proj.w, bias=bw.proj.b, residual=x)
-    y2, mean2, rstd2 = ops.layernorm_fwd(x1, bw.norm2.g, bw.norm2.b, LN_EPS, save_stats=save)
-    # u: the fc1 epilogue saves gelu'(pre-activation) here (not the pre-activation): all the backward needs from it
-    u = torch.empty((x.shape[0], bw.fc1.w.shape[0]), dtype=torch.bfloat16, device=x.device) if save else None
-    g = ops.gemm_nt(y2, bw.fc1.w, bias=bw.fc1.b, aux_out=u, epilogue=ops.EPI_GELU)
+    y2 = mean2 = rstd2 = u = None
+    if fold is not None:
+        g = ops.gemm_nt_lnfold(x1, fold.w_fc1, fold.b_fc1, ops.ln_rowstats(x1, LN_EPS), fold.c_fc1, epilogue=ops.EPI_GELU)
+    else:
+        y2, mean2, rstd2 = ops.layernorm_fwd(x1, bw.norm2.g, bw.norm2.b, LN_EPS, save_stats=save)
+        # u: the fc1 epilogue saves gelu'(pre-activation) here (not the pre-activation): all the backward needs from it
+        u = torch.empty((x.shape[0], bw.fc1.w.shape[0]), dtype=torch.bfloat16, device=x.device) if save else None
+        g = ops.gemm_nt(y2, bw.fc1.w, bias=bw.fc1.b, aux_out=u, epilogue=ops.EPI_GELU)
     x2 = ops.gemm_nt(g, bw.fc2.w, bias=bw.fc2.b, residual=x1)
     saved = (x, y1, mean1, rstd1, qkv, o, lses, x1, y2, mean2, rstd2, u, g) if save else None
     return x2, saved
@@ -331,8 +348,9 @@ def encoder_forward(ew: EncoderW, clips, masks: Optional[List[torch.Tensor]], sa
         x, saved_blocks = chain.blocks_forward(x, ew, segs, save, ws_tag, LN_EPS, gemm_flags=gemm_flags, gates=gates)
     else:
         saved_blocks = []
-        for bw in ew.blocks:
-            x, sv = block_forward(x, bw, segs, ew.heads, save)
+        folds = ew.folds if (ew.folds is not None and not save) else None
+        for bi, bw in enumerate(ew.blocks):
+            x, sv = block_forward(x, bw, segs, ew.heads, save, fold=None if folds is None else folds[bi])
             saved_blocks.append(sv)
     if not final_norm:
         return x, segs, None

@@ -57,6 +57,31 @@ class _TargetArena:
     def refresh_bf16(self):
         ops.cast_bf16(self.P, self.Pb)
 
+    # ---- LayerNorms folded into the qkv / fc1 GEMMs of the target forward (vj_blocks_fwd_lnfold)
+    def make_folds(self, depth):
+        """One FoldW per block, refreshed in place from the fp32 target weights after every EMA update."""
+        from .weights import FoldW
+        self.folds = []
+        for i in range(depth):
+            wq, w1 = self.f32(f"enc.blocks.{i}.attn.qkv.weight"), self.f32(f"enc.blocks.{i}.mlp.fc1.weight")
+            mk = lambda n: torch.empty(n, dtype=torch.float32, device=self.device)
+            self.folds.append(FoldW(torch.empty_like(wq, dtype=torch.bfloat16), mk(wq.shape[0]), mk(wq.shape[0]),
+                                    torch.empty_like(w1, dtype=torch.bfloat16), mk(w1.shape[0]), mk(w1.shape[0])))
+        self.refresh_folds(0, depth)
+        return self.folds
+
+    def refresh_folds(self, b0, b1):
+        """Wf = bf16(W * gamma), c = row sums of Wf, b' = b + W beta for blocks [b0, b1) -- two launches per block, on the
+        current stream (the update stream when the update is deferred: before the range's gate event)."""
+        if getattr(self, "folds", None) is None:
+            return
+        for i in range(b0, b1):
+            f, pre = self.folds[i], f"enc.blocks.{i}."
+            ops.ln_fold_weights(self.f32(pre + "attn.qkv.weight"), self.f32(pre + "attn.qkv.bias"), self.f32(pre + "norm1.weight"),
+                                self.f32(pre + "norm1.bias"), f.w_qkv, f.c_qkv, f.b_qkv)
+            ops.ln_fold_weights(self.f32(pre + "mlp.fc1.weight"), self.f32(pre + "mlp.fc1.bias"), self.f32(pre + "norm2.weight"),
+                                self.f32(pre + "norm2.bias"), f.w_fc1, f.c_fc1, f.b_fc1)
+
 
 class StepOutput:
     """Losses and gradient statistics stay on the device until read (one host sync for all of them)."""
@@ -104,6 +129,7 @@ class StepOutput:
 
 import os as _os
 _OVERLAP_FWD = _os.environ.get("VJ_OVERLAP_FWD", "1") != "0"   # diagnostics: 0 = target forward on the main stream
+_LN_FOLD = _os.environ.get("VJ_LN_FOLD", "1") != "0"             # fold the target encoder's LayerNorms into its qkv / fc1 GEMMs
 _UPD_LOW_PRIO = _os.environ.get("VJ_UPD_LOW_PRIO", "0") == "1"   # the deferred update's stream at the device's lowest priority (A/B)
 # GEMM kernel selection of the EMA target encoder's forward (vj_blocks_fwd gemm_flags: low 16 bits = flags, bits 16-23 = first
 # block they apply to); 0 = automatic everywhere
@@ -170,6 +196,10 @@ class Trainer:
                                   train=True)
         self.tw = encoder_views(self.tarena, "enc.", self.tvit,
                                 self.tarena.frozen["enc.pos_embed"].reshape(self.tvit.num_patches, -1), train=False)
+        # LayerNorms of the EMA target encoder folded into its qkv / fc1 GEMMs (no LayerNorm launch, no LayerNorm output in HBM on
+        # the target path).  `ln_fold_target` may be flipped between steps (tools/abab.py).
+        self._target_folds = self.tarena.make_folds(len(self.tw.blocks)) if _LN_FOLD else None
+        self.ln_fold_target = _LN_FOLD
         # optimizer-facing view (schedulers write lr / weight_decay into these dicts, like torch param_groups);
         # order = the reference's: [enc decayed, pred decayed, enc no-decay, pred no-decay].  Like init_opt
         # (app/vjepa/utils.py:173-191) the groups are built from ALL named_parameters, so the frozen pos_embed /
@@ -202,6 +232,7 @@ class Trainer:
     def forward_target(self, clips, masks_pred):
         """h_i = apply_masks(F.layer_norm(target_encoder(clips)), masks_pred)  (train.py:419-429), fp32."""
         B = clips.shape[0]
+        self.tw.folds = self._target_folds if (self.ln_fold_target and self._target_folds is not None) else None
         x, _, _ = encoder_forward(self.tw, clips, None, save=False, final_norm=False, ws_tag=self._ws + "tgt",
                                   gemm_flags=_TGT_GEMM_FLAGS, gates=self._gate("enc"))
         N = self.tvit.num_patches
@@ -413,9 +444,13 @@ class Trainer:
             upd.wait_event(ready)
             gates = {"enc": [], "pred": []}
             with torch.cuda.stream(upd):
-                for which, first_block, ranges in self._plan:
+                n_enc = sum(1 for w, _, _ in self._plan if w == "enc")
+                firsts = [f for w, f, _ in self._plan if w == "enc"] + [len(self.tw.blocks)]
+                for pi, (which, first_block, ranges) in enumerate(self._plan):
                     for gi, lo, hi in ranges:
                         update(gi, lo, hi)
+                    if which == "enc" and self.ln_fold_target:   # the folded target weights of this range's blocks, before its gate
+                        T.refresh_folds(first_block, firsts[pi + 1] if pi + 1 <= n_enc else len(self.tw.blocks))
                     ev = torch.cuda.Event()
                     ev.record(upd)
                     gates[which].append((first_block, ev))
@@ -428,6 +463,8 @@ class Trainer:
         else:
             for gi, (lo, hi) in enumerate(A.group_ranges):
                 update(gi, lo, hi)
+            if self.ln_fold_target:
+                T.refresh_folds(0, len(self.tw.blocks))
             A.refresh_transposed()
         bump_generation()   # parameters changed behind torch's version counters: derived-weight caches must refresh
         for g in self.param_groups:
@@ -498,4 +535,5 @@ class Trainer:
         self.arena.refresh_bf16()
         self.arena.refresh_transposed()
         self.tarena.refresh_bf16()
+        self.tarena.refresh_folds(0, len(self.tw.blocks))
         bump_generation()

@@ -76,6 +76,17 @@ class BlockW:
 
 
 @dataclass
+class FoldW:
+    """One block's LayerNorms folded into the Linears that consume them (vj_lnfold_t): for trunks that never run backward."""
+    w_qkv: torch.Tensor                   # bf16 [3D, D] = bf16(W_qkv * norm1.weight)
+    c_qkv: torch.Tensor                   # fp32 [3D]  row sums of w_qkv
+    b_qkv: torch.Tensor                   # fp32 [3D]  qkv.bias + W_qkv norm1.bias
+    w_fc1: torch.Tensor                   # bf16 [Dh, D]
+    c_fc1: torch.Tensor
+    b_fc1: torch.Tensor
+
+
+@dataclass
 class EncoderW:
     patch: LinearW                        # Conv3d weight viewed [D, C*tub*p*p]
     pos: torch.Tensor                     # fp32 [N, D]
@@ -84,6 +95,7 @@ class EncoderW:
     heads: int = 1
     tubelet: int = 2
     patch_size: int = 16
+    folds: Optional[List[FoldW]] = None   # set (EMA target encoder, option ln_fold): the forward takes vj_blocks_fwd_lnfold
 
 
 @dataclass

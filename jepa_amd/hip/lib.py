@@ -34,6 +34,10 @@ class VjBlock(ctypes.Structure):            # vj_block_t
                 ("fc2", VjLinear)]
 
 
+class VjLnFold(ctypes.Structure):           # vj_lnfold_t
+    _fields_ = [("w_qkv", P), ("c_qkv", P), ("b_qkv", P), ("w_fc1", P), ("c_fc1", P), ("b_fc1", P)]
+
+
 class VjReduceSeg(ctypes.Structure):        # vj_reduce_seg_t
     _fields_ = [("part", P), ("out", P), ("P", I64), ("N", I64), ("stride", I64)]
 
@@ -102,6 +106,11 @@ SIGNATURES = {
     "vj_blocks_fwd_ws_bytes": (I64, [I64, I64, I64, I64, I64, I32]),
     "vj_blocks_fwd": (I32, [ctypes.POINTER(VjBlock), I64, P, P, I64, I64, I64, ctypes.POINTER(VjSeg), I64, F32, I32, I32,
                             P, I64, P]),
+    "vj_blocks_fwd_lnfold": (I32, [ctypes.POINTER(VjBlock), ctypes.POINTER(VjLnFold), I64, P, P, I64, I64, I64, ctypes.POINTER(VjSeg), I64,
+                                   F32, I32, P, I64, P]),
+    "vj_ln_rowstats": (I32, [P, P, I64, I64, F32, P]),
+    "vj_ln_fold_weights": (I32, [P, P, P, P, P, P, P, I64, I64, P]),
+    "vj_gemm_bf16_nt_lnfold": (I32, [P, I64, P, I64, P, I64, I64, I64, I64, P, P, P, I32, F32, I32, P]),
     "vj_blocks_bwd_ws_bytes": (I64, [I64, I64, I64, I64]),
     "vj_blocks_bwd": (I32, [ctypes.POINTER(VjBlock), I64, P, P, P, I64, I64, I64, ctypes.POINTER(VjSeg), I64, F32, F32,
                             P, I64, P, I64, I32, P, P, LAYER_CB, P]),

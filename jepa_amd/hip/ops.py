@@ -201,6 +201,49 @@ def gemm_nt(A, B, out=None, bias=None, residual=None, aux_in=None, aux_out=None,
     return out
 
 
+def ln_rowstats(x, eps, out=None, stream=None):
+    """rowstats[m] = {rstd_m, -mean_m * rstd_m} (fp32 [M, 2]) of the bf16 rows x [M, D]: the statistics pass of a LayerNorm that is
+    folded into the GEMM consuming it (vj_ln_rowstats)."""
+    lib = load_library()
+    _req(x, BF16, "x")
+    M, D = x.shape
+    rs = torch.empty((M, 2), dtype=F32, device=x.device) if out is None else out
+    check(lib.vj_ln_rowstats(_ptr(x), _ptr(rs), M, D, eps, _stream(stream)), "vj_ln_rowstats")
+    return rs
+
+
+def ln_fold_weights(W, b, gamma, beta, Wf=None, cvec=None, bf=None, stream=None):
+    """Wf = bf16(W * gamma) [N, K], cvec[n] = sum_k Wf[n, k], bf = b + W beta (vj_ln_fold_weights); W fp32 [N, K] contiguous."""
+    lib = load_library()
+    for t, nm in ((W, "W"), (gamma, "gamma"), (beta, "beta")):
+        if t.dtype != F32 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError(f"ln_fold_weights: {nm} must be a contiguous fp32 GPU tensor")
+    N, K = W.shape
+    Wf = torch.empty((N, K), dtype=BF16, device=W.device) if Wf is None else Wf
+    cvec = torch.empty((N,), dtype=F32, device=W.device) if cvec is None else cvec
+    bf = torch.empty((N,), dtype=F32, device=W.device) if bf is None else bf
+    check(lib.vj_ln_fold_weights(_ptr(W), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(Wf), _ptr(cvec), _ptr(bf), N, K, _stream(stream)),
+          "vj_ln_fold_weights")
+    return Wf, cvec, bf
+
+
+def gemm_nt_lnfold(X, Wf, bf, rowstats, cvec, out=None, epilogue=EPI_BF16, alpha=1.0, flags=None, stream=None):
+    """out = LayerNorm(X) W^T + b from the RAW bf16 rows X [M, K] (vj_gemm_bf16_nt_lnfold): Wf / cvec / bf from ln_fold_weights,
+    rowstats from ln_rowstats; epilogue EPI_BF16, EPI_GELU or EPI_QKV (first N/3 columns times alpha)."""
+    lib = load_library()
+    for t, nm in ((X, "X"), (Wf, "Wf")):
+        if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"gemm_nt_lnfold: {nm} must be a 2-D bf16 GPU tensor with unit inner stride")
+    M, K = X.shape
+    N = Wf.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=X.device)
+    check(lib.vj_gemm_bf16_nt_lnfold(_ptr(X), X.stride(0), _ptr(Wf), Wf.stride(0), _ptr(out), out.stride(0), M, N, K, _ptr(bf),
+                                     _ptr(rowstats), _ptr(cvec), epilogue, alpha, GEMM_FLAGS if flags is None else flags,
+                                     _stream(stream)), "vj_gemm_bf16_nt_lnfold")
+    return out
+
+
 WGRAD_WS_BYTES = 96 << 20
 GROUP_WS_BYTES = 192 << 20   # the grouped launch's workspace, same size as the C chain's (same split factor -> same bits)
 

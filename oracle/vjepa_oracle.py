@@ -205,12 +205,29 @@ def take_rows(x, idx):
     return torch.gather(x, 1, idx.unsqueeze(-1).expand(-1, -1, x.size(-1)))
 
 
-def _block_emu(x, w, pre, heads, eps):
-    """`block` with the HIP path's bf16 storage points (see the section comment above)."""
+# The EMA target encoder of the HIP path folds each LayerNorm into the Linear that consumes it (round 5, option ln_fold /
+# VJ_LN_FOLD, default on): the normalised rows are never stored, the bf16 operand of the GEMM is W * gamma instead of W, and the
+# bias absorbs W beta.  Same mathematics (LayerNorm(x) W^T + b), other rounding points; the emulation follows when this is True.
+EMU_TARGET_LN_FOLD = True
+
+
+def _folded_linear(x, W, b, gamma, beta, eps):
+    """LayerNorm(x; gamma, beta) W^T + b with the storage points of vj_gemm_bf16_nt_lnfold: x_hat in fp32 (not stored), bf16(W * gamma),
+    fp32 bias b + W beta.  No gradient flows here (the target encoder is frozen)."""
+    xh = F.layer_norm(x, (x.shape[-1],), None, None, eps)
+    return F.linear(xh, _r(W * gamma), b + W @ beta)
+
+
+def _block_emu(x, w, pre, heads, eps, fold=False):
+    """`block` with the HIP path's bf16 storage points (see the section comment above).  fold: the LayerNorms folded into the
+    qkv / fc1 GEMMs (target encoder, EMU_TARGET_LN_FOLD)."""
     B, S, D = x.shape
     hd = D // heads
-    y = _q(F.layer_norm(x, (D,), w[pre + "norm1.weight"], w[pre + "norm1.bias"], eps), True)
-    qkv = F.linear(y, _w(w[pre + "attn.qkv.weight"], True), w[pre + "attn.qkv.bias"])
+    if fold:
+        qkv = _folded_linear(x, w[pre + "attn.qkv.weight"], w[pre + "attn.qkv.bias"], w[pre + "norm1.weight"], w[pre + "norm1.bias"], eps)
+    else:
+        y = _q(F.layer_norm(x, (D,), w[pre + "norm1.weight"], w[pre + "norm1.bias"], eps), True)
+        qkv = F.linear(y, _w(w[pre + "attn.qkv.weight"], True), w[pre + "attn.qkv.bias"])
     q, k, v = qkv.reshape(B, S, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q = _q(q * (hd ** -0.5 * LOG2E), True)      # ONE rounding of c*q (qkv GEMM epilogue 4), base-2 logits from here on
     k, v = _q(k, True), _q(v, True)
@@ -220,16 +237,19 @@ def _block_emu(x, w, pre, heads, eps):
     att = _q((p @ v) / p.sum(dim=-1, keepdim=True), True)
     att = att.transpose(1, 2).reshape(B, S, D)
     x = _q(x + F.linear(att, _w(w[pre + "attn.proj.weight"], True), w[pre + "attn.proj.bias"]), True)
-    y = _q(F.layer_norm(x, (D,), w[pre + "norm2.weight"], w[pre + "norm2.bias"], eps), True)
-    u = _q(F.linear(y, _w(w[pre + "mlp.fc1.weight"], True), w[pre + "mlp.fc1.bias"]), True)
+    if fold:
+        u = _q(_folded_linear(x, w[pre + "mlp.fc1.weight"], w[pre + "mlp.fc1.bias"], w[pre + "norm2.weight"], w[pre + "norm2.bias"], eps), True)
+    else:
+        y = _q(F.layer_norm(x, (D,), w[pre + "norm2.weight"], w[pre + "norm2.bias"], eps), True)
+        u = _q(F.linear(y, _w(w[pre + "mlp.fc1.weight"], True), w[pre + "mlp.fc1.bias"]), True)
     g = _GeluStored.apply(u)
     return _q(x + F.linear(g, _w(w[pre + "mlp.fc2.weight"], True), w[pre + "mlp.fc2.bias"]), True)
 
 
-def block(x, w, pre, heads, eps=1e-6, emu=False):
+def block(x, w, pre, heads, eps=1e-6, emu=False, fold=False):
     """Block.forward (modules.py:114-120) with Attention (61-78, SDPA branch) and MLP (30-36)."""
     if emu:
-        return _block_emu(x, w, pre, heads, eps)
+        return _block_emu(x, w, pre, heads, eps, fold=fold)
     B, S, D = x.shape
     y = F.layer_norm(x, (D,), w[pre + "norm1.weight"], w[pre + "norm1.bias"], eps)
     qkv = F.linear(y, w[pre + "attn.qkv.weight"], w[pre + "attn.qkv.bias"])
@@ -249,7 +269,7 @@ def patchify(clips, tubelet, patch):
     return u.permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, -1, C * tubelet * patch * patch)
 
 
-def encoder_forward(w, clips, cfg, masks=None, emu=False, round_out=True):
+def encoder_forward(w, clips, cfg, masks=None, emu=False, round_out=True, fold=False):
     """VisionTransformer.forward (vision_transformer.py:159-195) for one mask (MultiMaskWrapper loops masks,
     multimask.py:17-26).  Returns [B, K or N, D] after the final norm.  emu: bf16 storage emulation; round_out=False
     leaves the final norm's output in fp32 (the HIP target path fuses it with the following F.layer_norm in fp32)."""
@@ -262,7 +282,7 @@ def encoder_forward(w, clips, cfg, masks=None, emu=False, round_out=True):
     if masks is not None:
         x = take_rows(x, masks)
     for i in range(cfg["depth"]):
-        x = block(x, w, f"blocks.{i}.", cfg["heads"], emu=emu)
+        x = block(x, w, f"blocks.{i}.", cfg["heads"], emu=emu, fold=fold and emu)
     return _q(F.layer_norm(x, (D,), w["norm.weight"], w["norm.bias"], 1e-6), emu and round_out)
 
 
@@ -325,7 +345,7 @@ def forward_all(enc_w, pred_w, tgt_w, clips, masks_enc, masks_pred, cfg, emu=Fal
     """forward_target + forward_context, train.py:419-438."""
     D = cfg["embed_dim"]
     with torch.no_grad():
-        h = encoder_forward(tgt_w, clips, cfg, emu=emu, round_out=False)
+        h = encoder_forward(tgt_w, clips, cfg, emu=emu, round_out=False, fold=EMU_TARGET_LN_FOLD)
         h = F.layer_norm(h, (D,))  # eps 1e-5, no affine (train.py:426)
         h_list = [take_rows(h, mp) for mp in masks_pred]
     z_enc = [encoder_forward(enc_w, clips, cfg, me, emu=emu) for me in masks_enc]

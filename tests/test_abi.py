@@ -49,8 +49,8 @@ def test_chain_workspace_queries_and_host_side_validation():
     M, D, H, n = 10560, 1024, 16, 24
     save = lib.vj_blocks_fwd_ws_bytes(M, D, 4 * D, H, n, 1)
     nosave = lib.vj_blocks_fwd_ws_bytes(M, D, 4 * D, H, n, 0)
-    per_block = 16 * D * 2 * M + 4 * 4 * M + 4 * H * M           # activations + mean/rstd x2 + lse
-    assert save % 256 == 0 and per_block * n <= save <= per_block * n + n * 13 * 256
+    per_block = 16 * D * 2 * M + 4 * 4 * M + 4 * H * M + 8 * M   # activations + mean/rstd x2 + lse + the folded LayerNorm's row statistics
+    assert save % 256 == 0 and per_block * n <= save <= per_block * n + n * 14 * 256
     assert per_block + 2 * D * M <= nosave <= per_block + 2 * D * M + 14 * 256
     assert lib.vj_blocks_fwd_ws_bytes(2 * M, D, 4 * D, H, n, 1) >= 2 * save - n * 13 * 256
     bwd = lib.vj_blocks_bwd_ws_bytes(M, D, 4 * D, H)

@@ -323,3 +323,95 @@ def test_independent_stream_picker():
     for _ in range(3):
         s = layers.independent_stream(torch.device(DEV), [main_s, side])
         assert layers.streams_concurrent(s, main_s) and layers.streams_concurrent(s, side)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm folded into the consuming GEMM
+def _ln_case(M, K, N, seed, adversarial):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(M, K, device=DEV, generator=g) * (1.0 + 2.0 * torch.rand(M, 1, device=DEV, generator=g))
+    if adversarial:          # rows whose mean dwarfs their spread (|mean| up to 60 sigma), and a few huge-variance rows
+        x = x + torch.randn(M, 1, device=DEV, generator=g) * 60.0
+        x[::7] *= 30.0
+    else:
+        x = x + torch.randn(M, 1, device=DEV, generator=g) * 0.5
+    x = x.to(torch.bfloat16)
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.03
+    b = torch.randn(N, device=DEV, generator=g) * 0.1
+    gamma = 1.0 + 0.3 * torch.randn(K, device=DEV, generator=g)
+    beta = 0.2 * torch.randn(K, device=DEV, generator=g)
+    return x, W, b, gamma, beta
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 1024, 3072), (2304 + 40, 1024, 4096), (300, 192, 576), (77, 96, 384), (1000, 384, 1152)])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_layernorm_folded_into_the_gemm(ops, M, K, N, adversarial):
+    """vj_ln_rowstats + vj_ln_fold_weights + vj_gemm_bf16_nt_lnfold against LayerNorm(x) W^T + b in float64 (from the same bf16 x):
+      * the row statistics are those of layernorm_fwd_kernel bit for bit; Wf = bf16(W gamma) exactly, c / b' to fp32 rounding;
+      * plain / q-scaled / GELU epilogues within the GEMM bound of the unfused path (rel-L2 4e-3) and never worse than 1.25x the
+        unfused HIP path (LayerNorm kernel -> bf16 -> GEMM), which rounds the activation once more;
+      * adversarial rows (|mean| ~ 60 sigma, 30x scale outliers): the epilogue's acc - mean * c cancels what the matrix pipe
+        accumulated of the row mean -- exact up to fp32 accumulation, so the bound holds there too (the value to watch is stated)."""
+    eps = 1e-6
+    x, W, b, gamma, beta = _ln_case(M, K, N, 61 + M, adversarial)
+    y_un, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps, save_stats=True)
+    rs = ops.ln_rowstats(x, eps)
+    assert torch.equal(rs[:, 0], rstd) and torch.equal(rs[:, 1], -mean * rstd)
+    Wf, c, bf_ = ops.ln_fold_weights(W, b, gamma, beta)
+    assert torch.equal(Wf, (W * gamma).to(torch.bfloat16))
+    assert float((c.double() - Wf.double().sum(1)).abs().max()) < 1e-4 * float(Wf.double().abs().sum(1).max())
+    assert float((bf_.double() - (b.double() + W.double() @ beta.double())).abs().max()) < 1e-5
+    xd = x.double()
+    ln = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + eps) * gamma.double() + beta.double()
+    ref = ln @ W.double().t() + b.double()
+    Wb = W.to(torch.bfloat16)
+    hd_scale = 0.125 * 1.4426950408889634
+    cases = [("plain", dict(epilogue=ops.EPI_BF16), ref, ops.gemm_nt(y_un, Wb, bias=b))]
+    if N % 12 == 0:
+        rq = ref.clone()
+        rq[:, :N // 3] *= hd_scale
+        cases.append(("qkv", dict(epilogue=ops.EPI_QKV, alpha=hd_scale), rq, ops.gemm_nt(y_un, Wb, bias=b, epilogue=ops.EPI_QKV, alpha=hd_scale)))
+    cases.append(("gelu", dict(epilogue=ops.EPI_GELU), torch.nn.functional.gelu(ref), ops.gemm_nt(y_un, Wb, bias=b, epilogue=ops.EPI_GELU)))
+    for name, kw, r, unfused in cases:
+        out = ops.gemm_nt_lnfold(x, Wf, bf_, rs, c, **kw)
+        torch.cuda.synchronize()
+        e_f = float((out.double() - r).norm() / r.norm())
+        e_u = float((unfused.double() - r).norm() / r.norm())
+        print(f"[ln-fold {M}x{K}x{N} {'adv' if adversarial else 'std'} {name}] rel-L2 folded {e_f:.2e} | unfused {e_u:.2e}")
+        assert e_f < 4e-3, (name, e_f, e_u)
+        assert e_f < 1.25 * e_u + 1e-4, (name, e_f, e_u)
+
+
+def test_target_forward_with_folded_layernorms():
+    """Trainer.forward_target with and without the fold on the same weights (ViT-Tiny 12 blocks, perturbed affine parameters):
+    both are bf16 evaluations of the same function -- rel-L2 between them at the bf16 level (2e-2 bound as against the oracle),
+    each within 2e-2 of the fp32 oracle, and the C chain bit-identical to the per-kernel Python chain in both modes."""
+    from jepa_amd.engine import layers
+    from oracle import vjepa_oracle as O
+    from tests.golden_util import rel_l2
+    from tests.step_util import oracle_cfg
+    tr, state, _, _, _ = build_trainer(TINY, 2, perturb_small=True)
+    assert tr._target_folds is not None
+    clips, me, mp = draw_batch(_gens(), 4, TINY, 21, 22)
+    cd, med, mpd = to_dev(clips, me, mp)
+    hs = {}
+    for fold in (True, False):
+        tr.ln_fold_target = fold
+        for c_chain in (True, False):
+            layers.USE_C_CHAIN = c_chain
+            try:
+                hs[(fold, c_chain)] = [t.clone() for t in tr.forward_target(cd, mpd)]
+            finally:
+                layers.USE_C_CHAIN = True
+        for a, b in zip(hs[(fold, True)], hs[(fold, False)]):
+            assert torch.equal(a, b), ("C chain vs Python chain", fold)
+    import torch.nn.functional as F
+    with torch.no_grad():
+        h = O.encoder_forward(state["tgt"], clips, oracle_cfg(TINY, 2))
+        h = F.layer_norm(h, (TINY["embed_dim"],))
+        ref = [O.take_rows(h, m) for m in mp]
+    for i in range(len(mp)):
+        e_fold = rel_l2(hs[(True, True)][i].float().cpu().reshape(ref[i].shape), ref[i])
+        e_plain = rel_l2(hs[(False, True)][i].float().cpu().reshape(ref[i].shape), ref[i])
+        e_between = rel_l2(hs[(True, True)][i].float().cpu(), hs[(False, True)][i].float().cpu())
+        print(f"[target fold] mask {i}: vs fp32 oracle folded {e_fold:.2e} | unfused {e_plain:.2e} | folded vs unfused {e_between:.2e}")
+        assert e_fold < 2e-2 and e_plain < 2e-2 and e_between < 2e-2
