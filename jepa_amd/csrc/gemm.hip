@@ -374,6 +374,7 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.raster = 0;
   a.lnf_rs = lnf_rs;
   a.lnf_c = lnf_c;
+  a.dyn_slot = -1;
   a.qscale = qscale;
   a.qcols = qscale != 0.f ? N / 3 : 0;
   switch (epilogue) {
@@ -444,6 +445,7 @@ extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const vo
     a.raster = 0;
     a.lnf_rs = nullptr;
     a.lnf_c = nullptr;
+    a.dyn_slot = -1;
     const int rc = vj_gemm_launch_8phase_persist(a, EPI_DGELU, stream);
     if (rc != -100) {
       *fused = (rc == 0);

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
   p.gelu_lp = 0;
   p.lnf_rs = nullptr;
   p.lnf_c = nullptr;
+  p.dyn_slot = -1;
   p.raster = 0;
   p.qscale = 0.f;
   p.qcols = 0;
@@ -396,6 +397,7 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
   b.gelu_lp = 0;
   b.lnf_rs = nullptr;
   b.lnf_c = nullptr;
+  b.dyn_slot = -1;
   b.raster = 0;
   b.qscale = 0.f;
   b.qcols = 0;

@@ -34,6 +34,7 @@
 // Requirements (checked by the launcher, otherwise the one-tile kernel runs): bf16 output epilogues, M, N >= 256,
 // K % 64 == 0, K >= 256, more tiles than CUs, 16-byte-aligned rows of C (and aux), C not aliasing the residual.
 #include <type_traits>
+#include <atomic>
 #include "gemm_common.hpp"
 #include "options.hpp"
 
@@ -42,6 +43,20 @@
 #define PP_STAGE_PER_WAVE 4096
 
 namespace {
+
+// ---- dynamic tile hand-out (round 5, option gemm_dyn) -----------------------------------------------------------------------
+// The static lists give every workgroup of an XCD the same number of tiles.  In the two-stream step a launch rarely gets its CUs at
+// the same time -- the other stream's kernel frees them one workgroup at a time -- and a workgroup that starts late still walks its
+// full list while the CUs of the early ones go idle (or to a kernel that is not on the critical path).  Here only the first TWO tiles
+// of a workgroup are static (pos, pos + wgs_x of its XCD's band); every further tile is claimed from a per-XCD counter, two tiles
+// ahead: the claim is issued with the epilogue's other loads (it returns under the epilogue's own vmcnt(0): no new wait), handed to
+// the other seven waves through one LDS word of wave 0's staging area (idle outside the epilogue) and read after the first barrier
+// of the next tile -- early enough for that tile's tail to prefetch the claimed tile's operands.  The band order is unchanged (an
+// XCD still works on ~32 consecutive tiles of it) and every tile is computed exactly as before: outputs are bit-identical.
+// Counters: PP_DYN_SLOTS slots of 16 ints in a zero-initialised device global; a launch takes the next slot (host counter), the last
+// workgroup to finish zeroes it again; a slot is reused 1024 launches later.
+#define PP_DYN_SLOTS 1024
+__device__ int g_pp_dyn[PP_DYN_SLOTS][16];   // [slot][0..7 next tile per XCD | 8 finished workgroups]
 
 __device__ __forceinline__ void pp_bar() {
   asm volatile("" ::: "memory");
@@ -110,8 +125,21 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   const int band0 = xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx;
   const int band_n = qx + (xcd < rx ? 1 : 0);
   const int wgs_x = (G - xcd + 7) >> 3;               // workgroups of this launch that sit on XCD `xcd`
-  if (pos >= band_n) return;                          // (only when there are fewer tiles than workgroups)
-  const int my_tiles = (band_n - pos + wgs_x - 1) / wgs_x;
+  const bool dyn = SCHED == 4 && p.dyn_slot >= 0;      // workgroup-uniform (kernel argument)
+  auto dyn_finish = [&]() __attribute__((always_inline)) {   // the last workgroup to leave zeroes the launch's counter slot
+    if (dyn && tid == 0) {
+      int* ctr = g_pp_dyn[p.dyn_slot];
+      const int old = __hip_atomic_fetch_add(ctr + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) __hip_atomic_store(ctr + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (pos >= band_n) {                                // (only when there are fewer tiles than workgroups)
+    dyn_finish();
+    return;
+  }
 
   const int nk = (int)(p.K / 64);
   const int64_t lda2 = p.lda * 2, ldb2 = p.ldb * 2;
@@ -359,13 +387,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   issue(K_B1{}, cur, 1, 1);
   pp_wait<0>();
 
-  for (int ti = 0; ti < my_tiles; ti++) {
-    const bool has_next = ti + 1 < my_tiles;   // workgroup-uniform
-    int64_t m0n, n0n;
-    int tm_next;
-    pp_tile_origin(p, band0 + pos + (has_next ? ti + 1 : ti) * wgs_x, m0n, n0n, tm_next);
-    a0n = (const char*)(p.A + m0n * p.lda);
-    b0n = (const char*)(p.B + n0n * p.ldb);
+  // li_cur / li_nx: this workgroup's current and next tile, as positions in its XCD's band.  Static lists: li_nx = li_cur + wgs_x.
+  // Dynamic hand-out: the first two are static, from the third on li_nx comes out of the mailbox (claimed during the epilogue before last).
+  int li_cur = pos, li_nx = pos + wgs_x;
+  volatile int* mailbox = (volatile int*)(smem + PP_RING);   // first word of wave 0's staging area
+  bool first_tile = true;
+  while (true) {
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -374,6 +401,14 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     //      read >= 2 sections + one epilogue ago); every other part up to 5 landed before this wave's last vmcnt(0)
     if constexpr (SCHED == 8) issue(K_A1{}, cur, 1, h ^ 1);   // (SCHED = 4 issues it in LX(0))
     pp_bar();
+    if (dyn && !first_tile) li_nx = __builtin_amdgcn_readfirstlane(*mailbox);   // written by wave 0 before it arrived at the barrier above
+    first_tile = false;
+    const bool has_next = li_nx < band_n;   // workgroup-uniform
+    int64_t m0n, n0n;
+    int tm_next;
+    pp_tile_origin(p, band0 + (has_next ? li_nx : li_cur), m0n, n0n, tm_next);
+    a0n = (const char*)(p.A + m0n * p.lda);
+    b0n = (const char*)(p.B + n0n * p.ldb);
     if (late_group) pp_bar();
     read_a(ra0, smem + ((h ^ 1) * 4 + 3) * PP_PART);   // L(-1): A0(0)
     pp_bar();
@@ -410,16 +445,33 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
       const int efrow = elane & 15, efg = elane >> 4;
       pp_wait<0>();
+      // dynamic hand-out: claim the tile AFTER the next one now.  Wave 0's epilogue issues the fetch-and-increment next to its bias
+      // loads (gemm_common.hpp EpiClaim): the claim's round trip hides under the wait those loads need anyway.
       // (column sums, EPI_DGELU with p.colpart: a shifted edge tile owns only its rows >= tm * 256; slot = 2 tm + wave row)
-      (void)gemm_epilogue_try_staged<EPI, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
-                                             smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
-                                             tm_cur * 2 + wm);
+      if constexpr (SCHED == 4) {
+        EpiClaim ec{(dyn && has_next && wave_u == 0) ? g_pp_dyn[p.dyn_slot] + xcd : nullptr, 0};
+        (void)gemm_epilogue_try_staged<EPI, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+                                               smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
+                                               tm_cur * 2 + wm, &ec);
+        if (ec.ctr != nullptr) {   // wave 0 is done with its staging area until its next epilogue
+          *mailbox = 2 * wgs_x + ec.value;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the word is in LDS before this wave arrives at the next tile's first barrier
+        }
+      } else {
+        (void)gemm_epilogue_try_staged<EPI, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+                                               smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
+                                               tm_cur * 2 + wm);
+      }
     }
+    if (!has_next) break;
+    li_cur = li_nx;
+    li_nx = li_cur + wgs_x;      // (static lists; with the dynamic hand-out the mailbox overrides it after the next barrier)
     m0 = m0n;
     n0 = n0n;
     tm_cur = tm_next;
     pp_make_bases(cur, a0n, b0n, lda2, ldb2);
   }
+  dyn_finish();
 }
 
 template <int EPI>
@@ -473,6 +525,9 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   b.ws = nullptr;
   b.ktiles_per = (int)(a.K / 64);
   b.raster = vj_opt(VJ_OPT_GEMM_RASTER);
+  static std::atomic<unsigned> dyn_seq{0};
+  b.dyn_slot = (vj_opt(VJ_OPT_GEMM_DYN) != 0 && vj_opt(VJ_OPT_GEMM_SCHED) == 4 && !(a.dbg & 1))
+                   ? (int)(dyn_seq.fetch_add(1, std::memory_order_relaxed) % PP_DYN_SLOTS) : -1;
   if (b.raster == 511) {   // automatic: column groups of six for the encoder shapes (K >= 1024), the row-grouped order for the short-K predictor shapes
     b.raster = a.K >= 1024 ? 256 + 6 : 0;
   }

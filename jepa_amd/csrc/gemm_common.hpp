@@ -32,6 +32,8 @@ struct GemmArgs {
   //   out[m,n] = rstd_m * (acc[m,n] - mean_m * c[n]) + bias[n]  =  LayerNorm(x)[m,:] . W[n,:] + b[n]      (vj_gemm_bf16_nt_lnfold)
   const float* lnf_rs;   // [M][2] fp32, nullable (null: plain epilogue)
   const float* lnf_c;    // [N] fp32
+  int dyn_slot;          // persistent kernel: >= 0 -> tiles beyond the first two rounds are handed out by per-XCD atomic counters in slot
+                         // `dyn_slot` of g_pp_dyn (gemm8p.hip, option gemm_dyn); < 0 -> the static round-robin lists of rounds 3-4
 };
 
 
@@ -218,10 +220,17 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 // rows below `row_lo` -- the part of a SHIFTED edge tile that belongs to its neighbour -- are left out) and writes the 64
 // column sums to p.colpart[slot][n_base ..]: du = dY of fc1 is produced here, so fc1's bias gradient costs 64 packed FMAs + 64
 // DPP adds per wave tile instead of a second pass over du (colsum_bf16_kernel: 84 MB per ViT-L context block).
+// Dynamic tile hand-out of the persistent kernel (gemm8p.hip): wave 0 claims a tile index from a global counter INSIDE the epilogue,
+// next to its bias loads, so that the claim's round trip and the loads' overlap under the one vmcnt(0) the epilogue has anyway.
+struct EpiClaim {
+  int* ctr;    // counter to fetch-and-increment (wave-uniform; null: no claim)
+  int value;   // out: the counter's value before the increment (valid in every lane)
+};
+
 template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage,
-                                                     int64_t row_lo = 0, int slot = 0) {
+                                                     int64_t row_lo = 0, int slot = 0, EpiClaim* ec = nullptr) {
   // IPP = 16-row blocks per pass: 8 -> the whole wave tile in one 16 KB pass (stage = 16 KB per wave, the dead operand
   // ring of the one-tile-per-workgroup kernel); 2 -> four 4 KB passes (persistent kernel: the ring already holds the
   // next tile's first parts, the staging area is a separate 32 KB).
@@ -247,6 +256,22 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
   if constexpr (LNF) {
 #pragma unroll
     for (int j = 0; j < FN; j++) lc4[j] = *(const float4*)(p.lnf_c + ncl[j]);
+  }
+  // LNF: {rstd, -mean * rstd} of this lane's eight rows, ALL requested here, before the first store of the epilogue: a load issued
+  // between the stores would make its wait drain every store older than it (vmcnt counts stores), four times per tile
+  f32x2_t lrs[LNF ? 8 : 1];
+  if constexpr (LNF) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      int64_t m = m_base + i * 16 + frow;
+      if constexpr (EDGE) m = m < p.M ? m : p.M - 1;
+      lrs[i] = *(const f32x2_t*)(p.lnf_rs + 2 * m);
+    }
+  }
+  if (ec != nullptr && ec->ctr != nullptr) {   // (wave-uniform) one lane claims; the wait below covers it together with the loads above
+    int v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(ec->ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ec->value = __builtin_amdgcn_readfirstlane(v);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
 
@@ -308,13 +333,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
   }
   const int row_first = (int)(row_lo - m_base) - frow;   // CSUM: block i of this lane counts iff i * 16 >= row_first
   if constexpr (HAS_OPND) load_row(0, opnd[0]);
-  f32x2_t lrs[2];   // LNF: {rstd, -mean * rstd} of this lane's row, fetched one row block ahead like the row operands
-  auto load_rs = [&](int i) {
-    int64_t m = m_base + i * 16 + frow;
-    if constexpr (EDGE) m = m < p.M ? m : p.M - 1;
-    return *(const f32x2_t*)(p.lnf_rs + 2 * m);
-  };
-  if constexpr (LNF) lrs[0] = load_rs(0);
 #pragma unroll
   for (int ps = 0; ps < FM / RPP; ps++) {
 #pragma unroll
@@ -322,9 +340,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       const int i = ps * RPP + ii;
       if constexpr (HAS_OPND) {
         if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
-      }
-      if constexpr (LNF) {
-        if (i + 1 < FM) lrs[(i + 1) & 1] = load_rs(i + 1);
       }
       f32x2_t mk2 = {1.f, 1.f};
       if constexpr (CSUM) {
@@ -335,7 +350,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       for (int j = 0; j < FN; j++) {
         f32x2_t v01, v23;
         if constexpr (LNF) {   // rstd * acc + (-mean * rstd) * c[n] + b'[n]
-          const f32x2_t r2 = {lrs[i & 1][0], lrs[i & 1][0]}, s2 = {lrs[i & 1][1], lrs[i & 1][1]};
+          const f32x2_t r2 = {lrs[i][0], lrs[i][0]}, s2 = {lrs[i][1], lrs[i][1]};
           v01 = __builtin_elementwise_fma((f32x2_t){acc[i][j][0], acc[i][j][1]}, r2,
                                           __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].x, lc4[j].y}, (f32x2_t){bias4[j].x, bias4[j].y}));
           v23 = __builtin_elementwise_fma((f32x2_t){acc[i][j][2], acc[i][j][3]}, r2,
@@ -422,7 +437,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
 template <int EPI, int IPP = 8, bool ALLOW_LNF = true>
 __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                          int64_t n_base, int frow, int fg, int lane, char* stage,
-                                                         int64_t row_lo = 0, int slot = 0) {
+                                                         int64_t row_lo = 0, int slot = 0, EpiClaim* ec = nullptr) {
   if constexpr (EPI == EPI_F32) {
     return false;
   } else {
@@ -436,7 +451,7 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     const bool edge = __builtin_amdgcn_readfirstlane((m_base + 128 > p.M) || (n_base + 64 > p.N));
     if constexpr (EPI == EPI_DGELU && IPP == 2) {   // persistent kernel (every tile interior): optional fused column sums
       if (p.colpart != nullptr && !edge) {
-        gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot);
+        gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
         return true;
       }
     }
@@ -444,19 +459,19 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
       if (p.lnf_rs != nullptr) {   // LayerNorm folded into this GEMM (workgroup-uniform; the launcher guarantees: no residual / aux_out)
         if constexpr (EPI == EPI_BF16) {
           if (p.qscale != 0.f && n_base < p.qcols) {
-            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
           } else {
-            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
           }
         } else {
           if (p.gelu_lp) {
-            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
           } else {
-            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
           }
         }
         return true;
@@ -464,29 +479,29 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     }
     if constexpr (EPI == EPI_BF16) {
       if (p.qscale != 0.f && n_base < p.qcols) {   // wave tiles that hold q columns only (the launcher guarantees: no residual)
-        if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-        else gemm_epilogue_staged<EPI, false, false, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+        else gemm_epilogue_staged<EPI, false, false, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
         return true;
       }
     }
     if constexpr (EPI == EPI_GELU) {
       if (p.gelu_lp) {   // workgroup-uniform (kernel argument)
         if (opt) {
-          if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-          else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+          else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
         } else {
-          if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
-          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
         }
         return true;
       }
     }
     if (opt) {
-      if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
-      else gemm_epilogue_staged<EPI, true, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+      else gemm_epilogue_staged<EPI, true, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
     } else if constexpr (EPI != EPI_DGELU) {
-      if (edge) gemm_epilogue_staged<EPI, false, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
-      else gemm_epilogue_staged<EPI, false, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      if (edge) gemm_epilogue_staged<EPI, false, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+      else gemm_epilogue_staged<EPI, false, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
     }
     return true;
   }

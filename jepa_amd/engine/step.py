@@ -129,7 +129,10 @@ class StepOutput:
 
 import os as _os
 _OVERLAP_FWD = _os.environ.get("VJ_OVERLAP_FWD", "1") != "0"   # diagnostics: 0 = target forward on the main stream
-_LN_FOLD = _os.environ.get("VJ_LN_FOLD", "1") != "0"             # fold the target encoder's LayerNorms into its qkv / fc1 GEMMs
+# Fold the target encoder's LayerNorms into its qkv / fc1 GEMMs (vj_blocks_fwd_lnfold).  Built, parity-tested and measured in round 5:
+# it removes the 48 LayerNorm launches of the target forward and their output traffic, but the heavier GEMM epilogue takes the gain
+# back (profiles/r05_ln_fold.md), so it is opt-in (VJ_LN_FOLD=1 or Trainer.set_ln_fold(True)).
+_LN_FOLD = _os.environ.get("VJ_LN_FOLD", "0") == "1"
 _UPD_LOW_PRIO = _os.environ.get("VJ_UPD_LOW_PRIO", "0") == "1"   # the deferred update's stream at the device's lowest priority (A/B)
 # GEMM kernel selection of the EMA target encoder's forward (vj_blocks_fwd gemm_flags: low 16 bits = flags, bits 16-23 = first
 # block they apply to); 0 = automatic everywhere
@@ -198,8 +201,10 @@ class Trainer:
                                 self.tarena.frozen["enc.pos_embed"].reshape(self.tvit.num_patches, -1), train=False)
         # LayerNorms of the EMA target encoder folded into its qkv / fc1 GEMMs (no LayerNorm launch, no LayerNorm output in HBM on
         # the target path).  `ln_fold_target` may be flipped between steps (tools/abab.py).
-        self._target_folds = self.tarena.make_folds(len(self.tw.blocks)) if _LN_FOLD else None
-        self.ln_fold_target = _LN_FOLD
+        self._target_folds = None
+        self.ln_fold_target = False
+        if _LN_FOLD:
+            self.set_ln_fold(True)
         # optimizer-facing view (schedulers write lr / weight_decay into these dicts, like torch param_groups);
         # order = the reference's: [enc decayed, pred decayed, enc no-decay, pred no-decay].  Like init_opt
         # (app/vjepa/utils.py:173-191) the groups are built from ALL named_parameters, so the frozen pos_embed /
@@ -345,6 +350,18 @@ class Trainer:
     @opt_step.setter
     def opt_step(self, v):
         self._step_dev.fill_(float(v))
+
+    def set_ln_fold(self, on):
+        """Switch the folded-LayerNorm form of the target forward on / off (between steps).  The folded weights are allocated on
+        first use and refreshed here; while the switch is on every optimizer step refreshes them after its EMA update."""
+        on = bool(on)
+        if on:
+            self.sync_update()
+            if self._target_folds is None:
+                self._target_folds = self.tarena.make_folds(len(self.tw.blocks))
+            else:
+                self.tarena.refresh_folds(0, len(self.tw.blocks))
+        self.ln_fold_target = on
 
     def _make_update_stream(self):
         """A stream for the deferred update that shares a hardware queue with neither the main nor the side stream (a shared

@@ -390,12 +390,11 @@ def test_target_forward_with_folded_layernorms():
     from tests.golden_util import rel_l2
     from tests.step_util import oracle_cfg
     tr, state, _, _, _ = build_trainer(TINY, 2, perturb_small=True)
-    assert tr._target_folds is not None
     clips, me, mp = draw_batch(_gens(), 4, TINY, 21, 22)
     cd, med, mpd = to_dev(clips, me, mp)
     hs = {}
     for fold in (True, False):
-        tr.ln_fold_target = fold
+        tr.set_ln_fold(fold)
         for c_chain in (True, False):
             layers.USE_C_CHAIN = c_chain
             try:
@@ -415,3 +414,83 @@ def test_target_forward_with_folded_layernorms():
         e_between = rel_l2(hs[(True, True)][i].float().cpu(), hs[(False, True)][i].float().cpu())
         print(f"[target fold] mask {i}: vs fp32 oracle folded {e_fold:.2e} | unfused {e_plain:.2e} | folded vs unfused {e_between:.2e}")
         assert e_fold < 2e-2 and e_plain < 2e-2 and e_between < 2e-2
+
+
+# ------------------------------------------------------------------------------------------ dynamic tile hand-out of the persistent GEMM
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("M,N,K", [(37632, 1024, 256), (5000, 1288, 256), (10560, 3072, 1088), (2304 + 40, 2600, 320), (58560, 384, 384)])
+def test_dynamic_tile_handout_is_bit_identical(ops, M, N, K):
+    """Option gemm_dyn = 1: tiles beyond a workgroup's first two come from per-XCD atomic counters (gemm8p.hip) instead of the static
+    round-robin lists.  Another assignment of the same tiles to workgroups: the bits of the static lists, for every epilogue, with the
+    trimmed and with the full grid -- and still after 1100 back-to-back launches (the 1024 counter slots wrap; each launch's last
+    workgroup must have zeroed its slot)."""
+    g = torch.Generator(device=DEV).manual_seed(59)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    aux = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(torch.bfloat16)
+
+    def run_all():
+        outs = [ops.gemm_nt(A, W, bias=bias), ops.gemm_nt(A, W, bias=bias, residual=res), ops.gemm_nt(A, W, bias=bias, epilogue=ops.EPI_GELU)]
+        u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        outs.append(ops.gemm_nt(A, W, bias=bias, aux_out=u, epilogue=ops.EPI_GELU))
+        outs.append(u)
+        du, colpart = ops.gemm_dgelu_colsum(A, W, aux)
+        outs.append(du)
+        if colpart is not None:
+            outs.append(colpart)
+        torch.cuda.synchronize()
+        return outs
+    with _opt("gemm_dyn", 0):
+        ref = run_all()
+    for persist in (1, 2):
+        with _opt("gemm_dyn", 1), _opt("gemm_persist", persist):
+            for rep in range(3):
+                got = run_all()
+                for i, (a, b) in enumerate(zip(ref, got)):
+                    assert torch.equal(a, b), (persist, rep, i, int((a != b).sum()))
+    if M == 5000:
+        with _opt("gemm_dyn", 1):
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            for _ in range(1100):
+                ops.gemm_nt(A, W, bias=bias, out=out)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref[0])
+
+
+def test_folded_target_forward_vs_the_emulating_oracle():
+    """The D = 64 fixture model (weights and inputs produced by the REAL reference): target features h with the LayerNorms folded
+    against the oracle that emulates the fold's storage points (oracle.EMU_TARGET_LN_FOLD: x_hat kept in fp32, bf16(W gamma), fp32
+    bias b + W beta) -- 1e-3 like the unfused path against its emulation (tests/test_emu_parity_gpu.py), and within 2e-2 of the fp32 oracle."""
+    import copy
+    from oracle import vjepa_oracle as O
+    from jepa_amd.engine.step import Trainer
+    from tests.golden_util import HP, MICRO, load_micro, micro_weights, rel_l2, step_inputs
+    from tests.test_step_gpu import build_micro_modules, load_into
+    z = load_micro()
+    enc_w, pred_w = micro_weights(z)
+    enc, pred = build_micro_modules()
+    load_into(enc, enc_w)
+    load_into(pred, pred_w)
+    tgt = copy.deepcopy(enc)
+    for p in tgt.parameters():
+        p.requires_grad = False
+    enc.to(DEV), pred.to(DEV), tgt.to(DEV)
+    tr = Trainer(enc, pred, tgt, loss_exp=HP["loss_exp"], reg_coeff=HP["reg_coeff"], betas=HP["betas"], eps=HP["eps"], device=DEV)
+    tr.set_ln_fold(True)
+    state = dict(enc=enc_w, pred=pred_w, tgt={k: v.clone() for k, v in enc_w.items()}, opt={})
+    clips, me, mp = step_inputs(z, 0)
+    o32, _ = O.step_grads(state, clips, me, mp, dict(MICRO), HP)
+    old = O.EMU_TARGET_LN_FOLD
+    O.EMU_TARGET_LN_FOLD = True
+    try:
+        oe, _ = O.step_grads(state, clips, me, mp, dict(MICRO), HP, emu=True)
+    finally:
+        O.EMU_TARGET_LN_FOLD = old
+    cd, med, mpd = to_dev(clips, me, mp)
+    h = tr.forward_target(cd, mpd)
+    for i in range(len(mp)):
+        eh, e32 = rel_l2(h[i].cpu(), oe["h"][i]), rel_l2(h[i].cpu(), o32["h"][i])
+        print(f"[micro, folded target] mask {i}: h vs the fold-emulating oracle {eh:.2e} (fp32 oracle {e32:.2e})")
+        assert eh < 1e-3 and e32 < 2e-2, (i, eh, e32)

@@ -9,7 +9,7 @@ per-arm median / min ms per step and the paired per-round delta against arm 0 (m
 
     python tools/abab.py --arms "base;4w:gemm_4w=1;tn:wgrad_tn=1" --rounds 6 --steps 6
 host-side switches:  no_overlap=1 (single stream), overlap_fwd=0 (target forward on the main stream), upd_overlap=0 (the fused
-                     AdamW / EMA update on the main stream, as rounds 1-4 ran it), ln_fold=0 (the target encoder with LayerNorm launches),
+                     AdamW / EMA update on the main stream, as rounds 1-4 ran it), ln_fold=1 (the target encoder's LayerNorms folded into its qkv / fc1 GEMMs),
                      tgt_flags=F (GEMM selection of the target encoder: flags | first block << 16, e.g. 786688 = 0x100 from block 12)
 """
 import argparse
@@ -82,11 +82,10 @@ def main():
         step_mod._OVERLAP_FWD = bool(opts.get("overlap_fwd", 1))
         trainer.sync_update()
         trainer.overlap_update = bool(opts.get("upd_overlap", 1))
-        fold = bool(opts.get("ln_fold", 1)) and trainer._target_folds is not None   # the target encoder's LayerNorms folded into its GEMMs
-        if fold and not trainer.ln_fold_target:
+        fold = bool(opts.get("ln_fold", 0))                        # 1: the target encoder's LayerNorms folded into its GEMMs
+        if fold != trainer.ln_fold_target:
             torch.cuda.synchronize()
-            trainer.tarena.refresh_folds(0, len(trainer.tw.blocks))                 # (not refreshed while the switch was off)
-        trainer.ln_fold_target = fold
+            trainer.set_ln_fold(fold)
         lowp = bool(opts.get("upd_prio", 0))                        # 1: the update stream at the device's lowest priority
         if lowp != getattr(trainer, "_upd_lowp", False):
             torch.cuda.synchronize()
