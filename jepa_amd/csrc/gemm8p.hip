@@ -73,8 +73,14 @@ __device__ __forceinline__ unsigned pp_lds(const char* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
 // LDS-DMA, SGPR base + 32-bit lane offset form, through inline assembly (the compiler neither counts it nor assumes an LDS write)
+template <bool NT = false>
 __device__ __forceinline__ void pp_dma(const char* sbase, unsigned voff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  // NT: non-temporal cache hint -- the line is the first candidate for eviction from the L2 (option gemm_nt: the operand that only
+  // STREAMS through an XCD's L2 under the current tile order, so that the panels the XCD re-uses round after round stay resident)
+  if constexpr (NT)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
 // the 8 wave-uniform row-group bases of one tile: A rows m0 + j*128 + mq*64, B rows n0 + j*128 + nq*32 (byte pointers at k = 0)
@@ -106,8 +112,10 @@ enum { PP_STEADY = 0, PP_HEAD0, PP_HEAD1, PP_TAIL0, PP_TAIL1 };
 
 // SCHED = 8: the round-3 schedule (four {load, compute} pairs per K-tile, 16 MFMAs per compute section);
 // SCHED = 4 (round 4): TWO pairs per K-tile, 32 MFMAs per compute section -- see k_tile4 below.
-template <int EPI, int SCHED>
+// NTM: bit 0 = the A operand's LDS-DMA carries the non-temporal hint, bit 1 = the B operand's (option gemm_nt)
+template <int EPI, int SCHED, int NTM = 0>
 __device__ __forceinline__ void pp_body(const GemmArgs& p) {
+  constexpr bool NTA = (NTM & 1) != 0, NTB = (NTM & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,12 +169,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     const unsigned slot = ring + (unsigned)(half * 4 + KIND) * PP_PART + dst_lane;
     const unsigned koff = (unsigned)kt * 128u;
     if constexpr (KIND == 0 || KIND == 1) {
-      pp_dma(bs.b[KIND][0], voff_b + koff, slot);
-      pp_dma(bs.b[KIND][1], voff_b + koff, slot + 512 * 16);
+      pp_dma<NTB>(bs.b[KIND][0], voff_b + koff, slot);
+      pp_dma<NTB>(bs.b[KIND][1], voff_b + koff, slot + 512 * 16);
     } else {
       constexpr int MQ = KIND == 2 ? 1 : 0;
-      pp_dma(bs.a[MQ][0], voff_a + koff, slot);
-      pp_dma(bs.a[MQ][1], voff_a + koff, slot + 512 * 16);
+      pp_dma<NTA>(bs.a[MQ][0], voff_a + koff, slot);
+      pp_dma<NTA>(bs.a[MQ][1], voff_a + koff, slot + 512 * 16);
     }
   };
   // the same for the NEXT tile (tail of the K loop, once per tile): only its two origin pointers are kept in SGPRs, the
@@ -176,12 +184,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     const unsigned slot = ring + (unsigned)(half * 4 + KIND) * PP_PART + dst_lane;
     const unsigned koff = (unsigned)kt * 128u;
     if constexpr (KIND == 0 || KIND == 1) {
-      pp_dma(b0n + (int64_t)(KIND * 32) * ldb2, voff_b + koff, slot);
-      pp_dma(b0n + (int64_t)(128 + KIND * 32) * ldb2, voff_b + koff, slot + 512 * 16);
+      pp_dma<NTB>(b0n + (int64_t)(KIND * 32) * ldb2, voff_b + koff, slot);
+      pp_dma<NTB>(b0n + (int64_t)(128 + KIND * 32) * ldb2, voff_b + koff, slot + 512 * 16);
     } else {
       constexpr int MQ = KIND == 2 ? 1 : 0;
-      pp_dma(a0n + (int64_t)(MQ * 64) * lda2, voff_a + koff, slot);
-      pp_dma(a0n + (int64_t)(128 + MQ * 64) * lda2, voff_a + koff, slot + 512 * 16);
+      pp_dma<NTA>(a0n + (int64_t)(MQ * 64) * lda2, voff_a + koff, slot);
+      pp_dma<NTA>(a0n + (int64_t)(128 + MQ * 64) * lda2, voff_a + koff, slot + 512 * 16);
     }
   };
   using K_B0 = std::integral_constant<int, 0>;
@@ -478,9 +486,9 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p) {
   pp_body<EPI, 8>(p);
 }
-template <int EPI>
+template <int EPI, int NTM = 0>
 __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_kernel(GemmArgs p) {
-  pp_body<EPI, 4>(p);
+  pp_body<EPI, 4, NTM>(p);
 }
 
 int g_num_cus = 0;   // CU count of the (homogeneous) GPUs of this node, read once
@@ -548,9 +556,18 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   if (vj_opt(VJ_OPT_GEMM_SCHED) == 4) {
     static VjPerDeviceOnce attr4_once;
     attr4_once([] {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     });
-    hipLaunchKernelGGL(gemm_nt_4phase_persist_kernel<EPI>, dim3(grid), dim3(512), smem, stream, b);
+    // option gemm_nt: 1 = the operand that streams through an XCD's L2 carries the non-temporal hint (A under a column-grouped tile
+    // order, B under a row-grouped one); 2 = the other one (A/B control); 0 = none
+    const int ntopt = vj_opt(VJ_OPT_GEMM_NT);
+    const bool colgrouped = (b.raster & 0x100) != 0;
+    const int ntm = ntopt == 0 ? 0 : ((ntopt == 1) == colgrouped ? 1 : 2);
+    if (ntm == 1) hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 1>), dim3(grid), dim3(512), smem, stream, b);
+    else if (ntm == 2) hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 2>), dim3(grid), dim3(512), smem, stream, b);
+    else hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, b);
   } else {
     hipLaunchKernelGGL(gemm_nt_8phase_persist_kernel<EPI>, dim3(grid), dim3(512), smem, stream, b);
   }

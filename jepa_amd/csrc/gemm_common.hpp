@@ -302,7 +302,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     for (int it = 0; it < RPP * 2; it++) {
       const u32x4_t v = *(const u32x4_t*)(stage + blk0 * 2048 + it * 1024 + rd_off[it & 1]);
       const int64_t m = m_base + row0 + it * 8 + rrow;
+#ifdef VJ_NT_STORE   // A/B build only (python -m jepa_amd.build nts -DVJ_NT_STORE=1): the outputs bypass L2 retention
+      if (col_ok && (!EDGE || m < p.M)) __builtin_nontemporal_store(v, (u32x4_t*)(out + m * ld + n_base + rch * 8));
+#else
       if (col_ok && (!EDGE || m < p.M)) *(u32x4_t*)(out + m * ld + n_base + rch * 8) = v;
+#endif
     }
   };
 

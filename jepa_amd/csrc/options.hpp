@@ -56,6 +56,8 @@ enum VjOpt {
                                // (profiles/r04_gemm_raster.md).  0 = the order of rounds 2-4 (groups of 8 row tiles).  Bit-identical results
   VJ_OPT_ATTN_DQ_QW,           // 16-query tiles per wave in the attention dQ kernel: 0 (default) = 2 (128 queries per workgroup); 4 = four at head_dim <= 32
                                // (256 queries per workgroup: half the LDS instructions per MFMA).  dqkv bit-identical; the dQ column partials regroup
+  VJ_OPT_GEMM_NT,              // non-temporal hint on the persistent NT GEMM's LDS-DMA: 1 = on the operand that only streams through an XCD's L2 under
+                               // the current tile order (A for column groups), 2 = on the other one (control), 0 = none.  Bit-identical results
   VJ_OPT_GEMM_DYN,             // 1: the persistent NT GEMM hands out every tile beyond a workgroup's first two from per-XCD atomic counters (gemm8p.hip);
                                // 0: static round-robin lists.  Bit-identical results
   VJ_OPT_ADAM_GRID,            // cap on the workgroup count of the guarded fused AdamW / EMA kernel (0 = none: 8 workgroups per CU); A/B of the

@@ -494,3 +494,25 @@ def test_folded_target_forward_vs_the_emulating_oracle():
         eh, e32 = rel_l2(h[i].cpu(), oe["h"][i]), rel_l2(h[i].cpu(), o32["h"][i])
         print(f"[micro, folded target] mask {i}: h vs the fold-emulating oracle {eh:.2e} (fp32 oracle {e32:.2e})")
         assert eh < 1e-3 and e32 < 2e-2, (i, eh, e32)
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 1288, 256), (10560, 3072, 1088)])
+def test_non_temporal_operand_hint_is_bit_identical(ops, M, N, K):
+    """Option gemm_nt (the LDS-DMA of one operand of the persistent GEMM carries the non-temporal cache hint): a cache policy, not
+    arithmetic -- the same bits, for both choices of the operand and both families of tile orders."""
+    g = torch.Generator(device=DEV).manual_seed(67)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+
+    def run_all():
+        outs = [ops.gemm_nt(A, W, bias=bias), ops.gemm_nt(A, W, bias=bias, residual=res), ops.gemm_nt(A, W, bias=bias, epilogue=ops.EPI_GELU)]
+        torch.cuda.synchronize()
+        return outs
+    ref = run_all()
+    for nt in (1, 2):
+        for raster in (260, 8):
+            with _opt("gemm_nt", nt), _opt("gemm_raster", raster):
+                for a, b in zip(ref, run_all()):
+                    assert torch.equal(a, b), (nt, raster)
