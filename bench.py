@@ -464,12 +464,12 @@ def main():
         # correction + WRITE_SIZE), committed under profiles/ -- counters cannot be collected from inside this process
         DOM = "gemm_nt_4phase_persist_kernel<0>"
         traffic, traffic_src = None, None
-        for pmc_name in ("r04_hbm_pmc.json",):
+        for pmc_name in ("r05_hbm_pmc.json", "r04_hbm_pmc.json"):   # newest first (round 5: taken at HEAD with the column-grouped tile order)
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and args.workload == "vitl16":
                 with open(pmc) as fjs:
                     tab = json.load(fjs)
-                ent = tab.get(DOM)
+                ent = tab.get(DOM) or tab.get("gemm_nt_4phase_persist_kernel<0, 0>")   # (a second template argument since round 5)
                 if ent:
                     traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/" + pmc_name
                     break
@@ -482,9 +482,6 @@ def main():
                           "timed region, two-stream execution); sub-objects from the instrumented single-stream pass",
                 "achieved": whole["achieved"], "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": whole["frac"],
                 "traffic": traffic, "traffic_unit": f"HBM bytes per launch of {DOM} (PMC)", "traffic_source": traffic_src,
-                "traffic_note": "PMC passes of trip 14, taken with the row-grouped tile order; the column-grouped order that is the default since "
-                                "(option gemm_raster = 260) lowers the fabric reads of the encoder shapes by 14-38 % (per-shape PMC table: "
-                                "profiles/r04_gemm_raster.md)",
                 "whole_step": whole,
                 "gemm_family": {"kernels": "gemm_nt_4phase_persist_kernel<0|1|2> (persistent 256x256 NT, two staggered wave groups, two "
                                            "32-MFMA sections per K-tile, cross-tile LDS-DMA prefetch), gemm_tn_8phase_kernel "

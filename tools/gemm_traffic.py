@@ -28,13 +28,20 @@ SHAPES = [  # (tag, M, N, K, epilogue, extra operand): the step's shapes (profil
     ("ctx dqkv", 10560, 1024, 3072, 0, None),
     ("prd qkv", 58560, 1152, 384, 0, None), ("prd proj +res", 58560, 384, 384, 0, "res"),
     ("prd fc1 gelu+u", 58560, 1536, 384, 1, "aux_out"), ("prd fc2 +res", 58560, 384, 1536, 0, "res"),
-    ("wg qkv", 3072, 1024, 10560, 3, None), ("wg proj", 1024, 1024, 10560, 3, None),
-    ("wg fc1", 4096, 1024, 10560, 3, None), ("wg fc2", 1024, 4096, 10560, 3, None),
-    ("wg p.fc1", 1536, 384, 58560, 3, None),
+    # weight gradients as the step launches them since round 3: the four of a block in ONE grouped launch (vj_gemm_bf16_tn_grouped);
+    # M = sum N1*N2 / N of the group (the row count of the per-shape tables), N, K = tokens
+    ("wg ctx block (4 in one launch)", 3072, 4096, 10560, 4, (1024, 4096)), ("wg prd block (4 in one launch)", 1152, 1536, 58560, 4, (384, 1536)),
 ]
 
 
+def group_problems(D, Dh):
+    """(N_out, K_in) of a block's four Linears: qkv, proj, fc1, fc2."""
+    return [(3 * D, D), (D, D), (Dh, D), (D, Dh)]
+
+
 def algorithmic_bytes(M, N, K, epi, extra):
+    if epi == 4:   # grouped weight gradients: eight distinct token-major operands read once, four fp32 gradients written once
+        return sum(2 * K * (n1 + n2) + 4 * n1 * n2 for n1, n2 in group_problems(*extra))
     b = 2 * M * K + 2 * N * K                      # operands, read once
     b += 4 * M * N if epi == 3 else 2 * M * N      # output, written once
     if extra in ("res", "aux_in"):
@@ -57,6 +64,16 @@ def run():
     mark_dst = torch.zeros(4096, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for tag, M, N, K, epi, extra in SHAPES:
+        if epi == 4:
+            probs = [(torch.randn(K, n1, device=dev, generator=g).to(torch.bfloat16), torch.randn(K, n2, device=dev, generator=g).to(torch.bfloat16),
+                      torch.empty(n1, n2, device=dev, dtype=torch.float32)) for n1, n2 in group_problems(*extra)]
+            flush = torch.randn(96 << 20, device=dev, generator=g)
+            del flush
+            torch.cuda.synchronize()
+            check(lib.vj_probe_copy(mark_src.data_ptr(), mark_dst.data_ptr(), 4096, st), "marker")
+            ops.gemm_wgrad_tn_grouped(probs, alpha=1.0, beta=0.0)
+            torch.cuda.synchronize()
+            continue
         A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
         B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
         bias = torch.randn(N, device=dev, generator=g)
@@ -91,7 +108,7 @@ def per_shape(d, counter):
         if "probe_copy" in name:
             cur = {"kb": 0.0, "kernels": [], "ns": 0.0}
             out.append(cur)
-        elif cur is not None and ("gemm" in name or "splitk_reduce" in name):
+        elif cur is not None and ("gemm" in name or "splitk_reduce" in name or "reduce_partials" in name):
             cur["kb"] += float(r["Counter_Value"])
             cur["kernels"].append(name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:44])
             cur["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
