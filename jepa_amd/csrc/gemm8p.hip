@@ -113,7 +113,8 @@ enum { PP_STEADY = 0, PP_HEAD0, PP_HEAD1, PP_TAIL0, PP_TAIL1 };
 // SCHED = 8: the round-3 schedule (four {load, compute} pairs per K-tile, 16 MFMAs per compute section);
 // SCHED = 4 (round 4): TWO pairs per K-tile, 32 MFMAs per compute section -- see k_tile4 below.
 // NTM: bit 0 = the A operand's LDS-DMA carries the non-temporal hint, bit 1 = the B operand's (option gemm_nt)
-template <int EPI, int SCHED, int NTM = 0>
+// PRE: how an epilogue with a row operand requests it (gemm_common.hpp gemm_epilogue_staged; option gemm_epi_pre)
+template <int EPI, int SCHED, int NTM = 0, int PRE = 0>
 __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   constexpr bool NTA = (NTM & 1) != 0, NTB = (NTM & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -458,9 +459,9 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
       // (column sums, EPI_DGELU with p.colpart: a shifted edge tile owns only its rows >= tm * 256; slot = 2 tm + wave row)
       if constexpr (SCHED == 4) {
         EpiClaim ec{(dyn && has_next && wave_u == 0) ? g_pp_dyn[p.dyn_slot] + xcd : nullptr, 0};
-        (void)gemm_epilogue_try_staged<EPI, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
-                                               smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
-                                               tm_cur * 2 + wm, &ec);
+        (void)gemm_epilogue_try_staged<EPI, 2, true, PRE>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+                                                          smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
+                                                          tm_cur * 2 + wm, &ec);
         if (ec.ctr != nullptr) {   // wave 0 is done with its staging area until its next epilogue
           *mailbox = 2 * wgs_x + ec.value;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the word is in LDS before this wave arrives at the next tile's first barrier
@@ -489,6 +490,10 @@ __global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p)
 template <int EPI, int NTM = 0>
 __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_kernel(GemmArgs p) {
   pp_body<EPI, 4, NTM>(p);
+}
+template <int EPI, int PRE>
+__global__ __launch_bounds__(512) void gemm_nt_4phase_persist_pre_kernel(GemmArgs p) {
+  pp_body<EPI, 4, 0, PRE>(p);
 }
 
 int g_num_cus = 0;   // CU count of the (homogeneous) GPUs of this node, read once
@@ -536,6 +541,7 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   static std::atomic<unsigned> dyn_seq{0};
   b.dyn_slot = (vj_opt(VJ_OPT_GEMM_DYN) != 0 && vj_opt(VJ_OPT_GEMM_SCHED) == 4 && !(a.dbg & 1))
                    ? (int)(dyn_seq.fetch_add(1, std::memory_order_relaxed) % PP_DYN_SLOTS) : -1;
+  b.epi_pre = vj_opt(VJ_OPT_GEMM_EPI_PRE);
   if (b.raster == 511) {   // automatic: column groups of six for the encoder shapes (K >= 1024), the row-grouped order for the short-K predictor shapes
     b.raster = a.K >= 1024 ? 256 + 6 : 0;
   }
@@ -565,6 +571,24 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
     const int ntopt = vj_opt(VJ_OPT_GEMM_NT);
     const bool colgrouped = (b.raster & 0x100) != 0;
     const int ntm = ntopt == 0 ? 0 : ((ntopt == 1) == colgrouped ? 1 : 2);
+    // option gemm_epi_pre: the kernels whose residual / dGELU epilogue requests its row operand up front (no such operand: the default kernel)
+    constexpr bool CAN_PRE = EPI == EPI_BF16 || EPI == EPI_DGELU;
+    const bool has_opnd = EPI == EPI_DGELU ? true : (b.res != nullptr && b.lnf_rs == nullptr);
+    if constexpr (CAN_PRE) {
+      if (b.epi_pre != 0 && has_opnd && ntm == 0) {
+        static VjPerDeviceOnce attrp_once;
+        attrp_once([] {
+          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        });
+        if (b.epi_pre == 1) hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 1>), dim3(grid), dim3(512), smem, stream, b);
+        else if (b.epi_pre == 2) hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 2>), dim3(grid), dim3(512), smem, stream, b);
+        else hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 3>), dim3(grid), dim3(512), smem, stream, b);
+        VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase, operand preload)");
+        return 0;
+      }
+    }
     if (ntm == 1) hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 1>), dim3(grid), dim3(512), smem, stream, b);
     else if (ntm == 2) hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 2>), dim3(grid), dim3(512), smem, stream, b);
     else hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, b);

@@ -34,6 +34,9 @@ struct GemmArgs {
   const float* lnf_c;    // [N] fp32
   int dyn_slot;          // persistent kernel: >= 0 -> tiles beyond the first two rounds are handed out by per-XCD atomic counters in slot
                          // `dyn_slot` of g_pp_dyn (gemm8p.hip, option gemm_dyn); < 0 -> the static round-robin lists of rounds 3-4
+  int epi_pre = 0;       // persistent kernel, epilogues with a row operand (residual / saved gelu'): 0 -> one 16-row block ahead (rounds 3-5);
+                         // 1 -> all eight blocks requested before the epilogue's vmcnt(0), MFMA layout; 2 -> the same as sixteen full-line
+                         // 16-byte loads, re-laid-out through the staging area (option gemm_epi_pre; bit-identical results)
 };
 
 
@@ -227,7 +230,14 @@ struct EpiClaim {
   int value;   // out: the counter's value before the increment (valid in every lane)
 };
 
-template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false, bool LNF = false>
+// PRE (round 5, persistent kernel only): how the row operand (residual / saved gelu') reaches the lanes.  0: block i + 1 is requested
+// while block i is computed -- but a block is ~100 vector instructions and a load takes 0.7 ... 2 us, so the eight requests of a
+// wave tile are a CHAIN of exposed latencies, and every request issued behind a pass's stores returns only after those stores are
+// acknowledged (in-order vmcnt).  1: all eight blocks are requested next to the bias, in front of the one vmcnt(0) the epilogue has
+// anyway (64 VGPRs: the K loop's fragment registers are dead here).  2: the same bytes as sixteen row-major 16-byte loads (eight full
+// 128-byte lines per instruction instead of sixteen 32-byte pieces), parked in the staging area pass by pass and read back in the
+// MFMA layout -- the mirror image of the output path.  Same values, same arithmetic: bit-identical outputs.
+template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false, bool LNF = false, int PRE = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage,
                                                      int64_t row_lo = 0, int slot = 0, EpiClaim* ec = nullptr) {
@@ -268,12 +278,34 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       lrs[i] = *(const f32x2_t*)(p.lnf_rs + 2 * m);
     }
   }
+  constexpr bool HAS_OPND = (EPI == EPI_DGELU) || (EPI == EPI_BF16 && HAS_OPT);
+  static_assert(PRE == 0 || (HAS_OPND && IPP == 2 && !EDGE), "operand preload: interior tiles of the persistent kernel with a row operand");
+  const bf16_t* opnd_p = (EPI == EPI_DGELU) ? p.aux_in : p.res;
+  const int64_t opnd_ld = (EPI == EPI_DGELU) ? p.ldaux : p.ldr;
+  const int rrow = lane >> 3, rch = lane & 7;   // row-major side: 8 lanes per 128-byte row, 8 rows per instruction
+  u32x2_t opnd_all[PRE == 1 ? FM : 1][FN];      // PRE 1: the whole wave tile's operand in the MFMA layout
+  u32x4_t opnd_rm[PRE >= 2 ? 2 * FM : 1];       // PRE 2: ... as sixteen row-major 16-byte pieces (rows it * 8 + rrow, chunk rch)
+  if constexpr (PRE == 1) {
+#pragma unroll
+    for (int i = 0; i < FM; i++) {
+      const bf16_t* base = opnd_p + (m_base + i * 16 + frow) * opnd_ld;
+#pragma unroll
+      for (int j = 0; j < FN; j++) opnd_all[i][j] = *(const u32x2_t*)(base + ncl[j]);
+    }
+  }
+  if constexpr (PRE >= 2) {
+#pragma unroll
+    for (int it = 0; it < 2 * FM; it++)
+      opnd_rm[it] = *(const u32x4_t*)(opnd_p + (m_base + it * 8 + rrow) * opnd_ld + n_base + rch * 8);
+  }
   if (ec != nullptr && ec->ctr != nullptr) {   // (wave-uniform) one lane claims; the wait below covers it together with the loads above
     int v = 0;
     if (lane == 0) v = __hip_atomic_fetch_add(ec->ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ec->value = __builtin_amdgcn_readfirstlane(v);
   }
-  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
+  // PRE 3: no blanket wait -- the compiler's own counted waits let pass ps start when ITS four operand loads (and the bias, and -- loads
+  // return in order -- every LDS-DMA issued before them) have landed, while the loads of the later passes are still in flight
+  if constexpr (PRE != 3) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
 
   // LDS addresses: write (MFMA layout) and read-back (row-major) sides of the same swizzled image
   int wr_off[FN];
@@ -282,13 +314,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
 #pragma unroll
     for (int j = 0; j < FN; j++) wr_off[j] = frow * 128 + (((j * 2 + (fg >> 1)) ^ key) << 4) + (fg & 1) * 8;
   }
-  const int rrow = lane >> 3, rch = lane & 7;   // read-back: 8 lanes per 128-byte row, 8 rows per instruction
-  int rd_off[2];
+  int rd_off[2];   // read-back (rrow, rch above): 8 lanes per 128-byte row, 8 rows per instruction
 #pragma unroll
   for (int par = 0; par < 2; par++) rd_off[par] = rrow * 128 + ((rch ^ ((par * 4 + (rrow >> 1)) & 7)) << 4);
   const bool col_ok = !EDGE || (n_base + rch * 8 < p.N);
 
-  constexpr bool HAS_OPND = (EPI == EPI_DGELU) || (EPI == EPI_BF16 && HAS_OPT);
   constexpr bool TWO_OUT = (EPI == EPI_GELU) && HAS_OPT;
   // 16-row blocks per pass.  Two outputs (GELU + saved derivative): half-size passes with BOTH images in the stage at once
   // (blocks 0 .. RPP-1: the derivative, RPP .. 2 RPP-1: the GELU output) -- holding the second output in registers until the
@@ -310,8 +340,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     }
   };
 
-  const bf16_t* opnd_p = (EPI == EPI_DGELU) ? p.aux_in : p.res;
-  const int64_t opnd_ld = (EPI == EPI_DGELU) ? p.ldaux : p.ldr;
   u32x2_t opnd[2][FN];
   auto load_row = [&](int i, u32x2_t* dst) {
     int64_t m = m_base + i * 16 + frow;
@@ -336,13 +364,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     for (int j = 0; j < FN; j++) cs01[j] = cs23[j] = (f32x2_t){0.f, 0.f};
   }
   const int row_first = (int)(row_lo - m_base) - frow;   // CSUM: block i of this lane counts iff i * 16 >= row_first
-  if constexpr (HAS_OPND) load_row(0, opnd[0]);
+  if constexpr (HAS_OPND && PRE == 0) load_row(0, opnd[0]);
 #pragma unroll
   for (int ps = 0; ps < FM / RPP; ps++) {
+    if constexpr (PRE >= 2) {   // this pass's operand rows: registers -> the stage image at the addresses the flush reads from
+#pragma unroll
+      for (int it = 0; it < RPP * 2; it++) *(u32x4_t*)(stage + it * 1024 + rd_off[it & 1]) = opnd_rm[ps * RPP * 2 + it];
+    }
 #pragma unroll
     for (int ii = 0; ii < RPP; ii++) {
       const int i = ps * RPP + ii;
-      if constexpr (HAS_OPND) {
+      if constexpr (HAS_OPND && PRE == 0) {
         if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
       }
       f32x2_t mk2 = {1.f, 1.f};
@@ -394,7 +426,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
             v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
           }
         } else if constexpr (EPI == EPI_DGELU) {
-          const u32x2_t u = opnd[i & 1][j];   // saved gelu'(u)
+          u32x2_t u;   // saved gelu'(u)
+          if constexpr (PRE == 1) u = opnd_all[i][j];
+          else if constexpr (PRE >= 2) u = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);   // (this lane overwrites the same 8 bytes below)
+          else u = opnd[i & 1][j];
           v01 *= (f32x2_t){bf_lo(u[0]), bf_hi(u[0])};
           v23 *= (f32x2_t){bf_lo(u[1]), bf_hi(u[1])};
           if constexpr (CSUM) {
@@ -402,7 +437,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
             cs23[j] = __builtin_elementwise_fma(v23, mk2, cs23[j]);
           }
         } else if constexpr (HAS_OPT) {
-          const u32x2_t r2 = opnd[i & 1][j];
+          u32x2_t r2;
+          if constexpr (PRE == 1) r2 = opnd_all[i][j];
+          else if constexpr (PRE >= 2) r2 = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);
+          else r2 = opnd[i & 1][j];
           v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
           v23 += (f32x2_t){bf_lo(r2[1]), bf_hi(r2[1])};
         }
@@ -438,7 +476,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
 // row-major stores cannot be used (N, ldc or the base pointers not 8-element aligned) and for fp32 outputs
 // (ALLOW_LNF = false: kernels that are never launched with a folded LayerNorm leave those variants out -- the 4-wave kernels'
 //  scalar register budget is spent on their twelve wave-uniform DMA bases)
-template <int EPI, int IPP = 8, bool ALLOW_LNF = true>
+template <int EPI, int IPP = 8, bool ALLOW_LNF = true, int PRE = 0>
 __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                          int64_t n_base, int frow, int fg, int lane, char* stage,
                                                          int64_t row_lo = 0, int slot = 0, EpiClaim* ec = nullptr) {
@@ -455,7 +493,15 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     const bool edge = __builtin_amdgcn_readfirstlane((m_base + 128 > p.M) || (n_base + 64 > p.N));
     if constexpr (EPI == EPI_DGELU && IPP == 2) {   // persistent kernel (every tile interior): optional fused column sums
       if (p.colpart != nullptr && !edge) {
-        gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
+        gemm_epilogue_staged<EPI, true, false, IPP, true, false, false, false, PRE>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
+        return true;
+      }
+    }
+    // row operand requested up front (option gemm_epi_pre -> a kernel of its own: the variant is a compile-time property, so that the
+    // default kernels' register allocation is untouched)
+    if constexpr (PRE != 0 && (EPI == EPI_DGELU || EPI == EPI_BF16) && IPP == 2) {
+      if (opt && !edge && (EPI == EPI_DGELU || p.lnf_rs == nullptr)) {
+        gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, PRE>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
         return true;
       }
     }

@@ -64,6 +64,9 @@ enum VjOpt {
                                // range-wise update running beside the next step's forward (Trainer(overlap_update)).  Same results
   VJ_OPT_WS_GUARD,             // diagnostics: 1 = 256-byte guard gaps behind every member of the chain workspaces, poisoned by the chain calls and
                                // inspected by vj_ws_guard_check (tests/test_round5_gpu.py).  Changes the workspace sizes: set it before the first step
+  VJ_OPT_GEMM_EPI_PRE,         // persistent NT GEMM, epilogues with a row operand (residual add, dGELU): 0 = the operand's 16-row blocks are requested one
+                               // block ahead; 1 = all eight before the epilogue's single vmcnt(0) (MFMA layout); 2 = as sixteen full-line 16-byte loads
+                               // re-laid-out through the staging area (gemm_common.hpp gemm_epilogue_staged PRE).  Bit-identical results
   VJ_OPT_COUNT
 };
 

@@ -516,3 +516,38 @@ def test_non_temporal_operand_hint_is_bit_identical(ops, M, N, K):
             with _opt("gemm_nt", nt), _opt("gemm_raster", raster):
                 for a, b in zip(ref, run_all()):
                     assert torch.equal(a, b), (nt, raster)
+
+
+# ------------------------------------------------------------------------------------------ row operand of the epilogue requested up front
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("M,N,K", [(37632, 1024, 256), (5000, 1288, 256), (10560, 1024, 1088), (2304 + 40, 2600, 320), (58560, 384, 384)])
+def test_epilogue_operand_preload_is_bit_identical(ops, M, N, K):
+    """Option gemm_epi_pre = 1 / 2: the residual (EPI_BF16) / the saved gelu' (EPI_DGELU, with and without fused column sums) of a wave
+    tile is requested in one go before the epilogue's vmcnt(0) -- in the MFMA layout (1) or as full-line 16-byte loads re-laid-out
+    through the staging area (2) -- instead of one 16-row block ahead.  Same values into the same arithmetic: the bits of the default,
+    also on shifted edge tiles, with the dynamic tile hand-out and with the full grid; launches without a row operand keep their kernel."""
+    g = torch.Generator(device=DEV).manual_seed(61)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    aux = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(torch.bfloat16)
+
+    def run_all():
+        outs = [ops.gemm_nt(A, W, bias=bias, residual=res), ops.gemm_nt(A, W, residual=res), ops.gemm_nt(A, W, bias=bias)]
+        du, colpart = ops.gemm_dgelu_colsum(A, W, aux)
+        outs.append(du)
+        if colpart is not None:
+            outs.append(colpart)
+        outs.append(ops.gemm_nt(A, W, aux_in=aux, epilogue=ops.EPI_DGELU))
+        torch.cuda.synchronize()
+        return outs
+    with _opt("gemm_epi_pre", 0):
+        ref = run_all()
+    for pre in (1, 2):
+        for persist, dyn in ((1, 0), (2, 0), (1, 1)):
+            with _opt("gemm_epi_pre", pre), _opt("gemm_persist", persist), _opt("gemm_dyn", dyn):
+                for rep in range(2):
+                    got = run_all()
+                    for i, (a, b) in enumerate(zip(ref, got)):
+                        assert torch.equal(a, b), (pre, persist, dyn, rep, i, int((a != b).sum()))
