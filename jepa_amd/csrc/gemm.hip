@@ -316,7 +316,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
   if (pipe == 3 && a.K % 64 == 0 && !reg_staged) {
     // persistent variant (gemm8p.hip): one workgroup per CU walks its tiles, next tile's operands prefetched under the
     // current tile, epilogue stores drained under the next K loop; bit-identical outputs.  Run-time option "gemm_persist".
-    if (EPI != EPI_F32 && vj_opt(VJ_OPT_GEMM_PERSIST) != 0 && a.dbg < 2) {
+    if (EPI != EPI_F32 && vj_opt(VJ_OPT_GEMM_PERSIST) != 0 && !(a.dbg & 2)) {
       const int rc = vj_gemm_launch_8phase_persist(a, EPI, stream);
       if (rc != -100) return rc;
     }

@@ -114,7 +114,10 @@ enum { PP_STEADY = 0, PP_HEAD0, PP_HEAD1, PP_TAIL0, PP_TAIL1 };
 // SCHED = 4 (round 4): TWO pairs per K-tile, 32 MFMAs per compute section -- see k_tile4 below.
 // NTM: bit 0 = the A operand's LDS-DMA carries the non-temporal hint, bit 1 = the B operand's (option gemm_nt)
 // PRE: how an epilogue with a row operand requests it (gemm_common.hpp gemm_epilogue_staged; option gemm_epi_pre)
-template <int EPI, int SCHED, int NTM = 0, int PRE = 0>
+// STAMP (diagnostics, gemm_dbg bit 2, tools/gemm_stamps.py): waves 0 and 4 (one per wave group) time the phases of every tile with
+// s_memtime -- tile start, K loop, wait for the cross-tile prefetch, epilogue, first barrier of the next tile -- and leave the sums in
+// the first bytes of C when the workgroup ends.  A kernel of its own: the product kernels carry no trace of it.
+template <int EPI, int SCHED, int NTM = 0, int PRE = 0, bool STAMP = false>
 __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   constexpr bool NTA = (NTM & 1) != 0, NTB = (NTM & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -122,6 +125,18 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_u >> 2, wn = wave_u & 3;
   const bool late_group = wave_u >= 4;        // waves 4-7 run one barrier interval behind waves 0-3
+  const bool stamper = STAMP && (wave_u & 3) == 0;   // wave-uniform
+  unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_prev = 0;
+  unsigned st_tiles = 0;
+  auto lap = [&](int k, bool count) __attribute__((always_inline)) {
+    if constexpr (STAMP) {
+      if (stamper) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (count) st_sum[k] += now - st_prev;
+        st_prev = now;
+      }
+    }
+  };
   const int frow = lane & 15, fg = lane >> 4;
 
   // ---- this workgroup's tile list: XCD x (= blockIdx & 7, the hardware's round-robin) owns a contiguous band of the
@@ -150,6 +165,10 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     return;
   }
 
+  if (p.stagger != 0) {   // (workgroup-uniform) option gemm_stagger: de-synchronise the launch's workgroups
+    const int n = (pos & 7) * p.stagger;
+    for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(4);
+  }
   const int nk = (int)(p.K / 64);
   const int64_t lda2 = p.lda * 2, ldb2 = p.ldb * 2;
   // per-thread byte offsets of a part's chunks (see gemm8.hip): row r0 (+ 64 j), chunk column swizzled by the row
@@ -410,6 +429,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     //      read >= 2 sections + one epilogue ago); every other part up to 5 landed before this wave's last vmcnt(0)
     if constexpr (SCHED == 8) issue(K_A1{}, cur, 1, h ^ 1);   // (SCHED = 4 issues it in LX(0))
     pp_bar();
+    lap(4, st_tiles != 0);       // [epilogue end -> past the next tile's first barrier: the skew between the eight waves]
     if (dyn && !first_tile) li_nx = __builtin_amdgcn_readfirstlane(*mailbox);   // written by wave 0 before it arrived at the barrier above
     first_tile = false;
     const bool has_next = li_nx < band_n;   // workgroup-uniform
@@ -422,6 +442,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     read_a(ra0, smem + ((h ^ 1) * 4 + 3) * PP_PART);   // L(-1): A0(0)
     pp_bar();
     pp_bar();
+    lap(0, st_tiles != 0);   // [tile start: first barrier -> K loop] (the first tile starts its clock here)
     if constexpr (SCHED == 8) {
       k_tile(M_HEAD0{}, 0, h);
       k_tile(M_HEAD1{}, 1, h ^ 1);
@@ -440,6 +461,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     }
     if (!late_group) pp_bar();   // the early group matches the late group's extra barrier
     h ^= (nk & 1);               // ring half of the next tile's K-tile 0
+    lap(1, true);                // [K loop]
 
     // ---- epilogue: staged through this wave's private 4 KB (the ring holds the next tile's parts).  Its first action
     //      (bias loads + s_waitcnt vmcnt(0)) also retires every LDS-DMA this wave has issued.
@@ -454,6 +476,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
       const int efrow = elane & 15, efg = elane >> 4;
       pp_wait<0>();
+      lap(2, true);              // [wait for the next tile's prefetched parts]
       // dynamic hand-out: claim the tile AFTER the next one now.  Wave 0's epilogue issues the fetch-and-increment next to its bias
       // loads (gemm_common.hpp EpiClaim): the claim's round trip hides under the wait those loads need anyway.
       // (column sums, EPI_DGELU with p.colpart: a shifted edge tile owns only its rows >= tm * 256; slot = 2 tm + wave row)
@@ -472,6 +495,8 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
                                                tm_cur * 2 + wm);
       }
     }
+    lap(3, true);                // [epilogue: bias (+ operand) latency, convert, stage, store issue]
+    if constexpr (STAMP) st_tiles++;
     if (!has_next) break;
     li_cur = li_nx;
     li_nx = li_cur + wgs_x;      // (static lists; with the dynamic hand-out the mailbox overrides it after the next barrier)
@@ -481,6 +506,16 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     pp_make_bases(cur, a0n, b0n, lda2, ldb2);
   }
   dyn_finish();
+  if constexpr (STAMP) {
+    if (stamper && lane == 0) {   // 64 bytes per (workgroup, wave group) at the start of C (every tile's real output is older than this)
+      unsigned long long* d = (unsigned long long*)p.C + ((int)blockIdx.x * 2 + (wave_u >> 2)) * 8;
+#pragma unroll
+      for (int k = 0; k < 5; k++) d[k] = st_sum[k];
+      d[5] = st_tiles;
+      d[6] = (unsigned long long)nk;
+      d[7] = 0x5354414d50ull;
+    }
+  }
 }
 
 template <int EPI>
@@ -494,6 +529,11 @@ __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_kernel(GemmArgs p)
 template <int EPI, int PRE>
 __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_pre_kernel(GemmArgs p) {
   pp_body<EPI, 4, 0, PRE>(p);
+}
+
+template <int EPI, int PRE>
+__global__ __launch_bounds__(512) void gemm_nt_4phase_persist_stamp_kernel(GemmArgs p) {
+  pp_body<EPI, 4, 0, PRE, true>(p);
 }
 
 int g_num_cus = 0;   // CU count of the (homogeneous) GPUs of this node, read once
@@ -542,6 +582,7 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   b.dyn_slot = (vj_opt(VJ_OPT_GEMM_DYN) != 0 && vj_opt(VJ_OPT_GEMM_SCHED) == 4 && !(a.dbg & 1))
                    ? (int)(dyn_seq.fetch_add(1, std::memory_order_relaxed) % PP_DYN_SLOTS) : -1;
   b.epi_pre = vj_opt(VJ_OPT_GEMM_EPI_PRE);
+  b.stagger = vj_opt(VJ_OPT_GEMM_STAGGER);
   if (b.raster == 511) {   // automatic: column groups of six for the encoder shapes (K >= 1024), the row-grouped order for the short-K predictor shapes
     b.raster = a.K >= 1024 ? 256 + 6 : 0;
   }
@@ -571,11 +612,41 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
     const int ntopt = vj_opt(VJ_OPT_GEMM_NT);
     const bool colgrouped = (b.raster & 0x100) != 0;
     const int ntm = ntopt == 0 ? 0 : ((ntopt == 1) == colgrouped ? 1 : 2);
-    // option gemm_epi_pre: the kernels whose residual / dGELU epilogue requests its row operand up front (no such operand: the default kernel)
+    if (a.dbg & 4) {   // diagnostics: the phase-stamping copy of the default kernel (operand preload 0 or 2 as the option says)
+      static VjPerDeviceOnce attrs_once;
+      attrs_once([] {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if constexpr (EPI != EPI_GELU)
+          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, EPI == EPI_GELU ? 0 : 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if constexpr (EPI == EPI_BF16) {
+          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        }
+      });
+      if (EPI == EPI_BF16 && b.epi_pre == 5) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, EPI == EPI_BF16 ? 5 : 4>), dim3(grid), dim3(512), smem, stream, b);
+      else if (EPI == EPI_BF16 && b.epi_pre == 6) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, EPI == EPI_BF16 ? 6 : 4>), dim3(grid), dim3(512), smem, stream, b);
+      else if (b.epi_pre >= 4) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, 4>), dim3(grid), dim3(512), smem, stream, b);
+      else if (b.epi_pre == 2 && EPI != EPI_GELU) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, EPI == EPI_GELU ? 0 : 2>), dim3(grid), dim3(512), smem, stream, b);
+      else hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, b);
+      VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase, phase stamps)");
+      return 0;
+    }
+    // option gemm_epi_pre: 1 ... 3 = the kernels whose residual / dGELU epilogue requests its row operand up front (no such operand: the default
+    // kernel); 4 = the pipelined epilogue passes, every epilogue
     constexpr bool CAN_PRE = EPI == EPI_BF16 || EPI == EPI_DGELU;
     const bool has_opnd = EPI == EPI_DGELU ? true : (b.res != nullptr && b.lnf_rs == nullptr);
+    if (b.epi_pre >= 4 && ntm == 0) {   // (5, 6: diagnostics, stamping kernel only -- the product kernel is the pipelined one)
+      static VjPerDeviceOnce attrq_once;
+      attrq_once([] {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      });
+      hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 4>), dim3(grid), dim3(512), smem, stream, b);
+      VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase, pipelined epilogue)");
+      return 0;
+    }
     if constexpr (CAN_PRE) {
-      if (b.epi_pre != 0 && has_opnd && ntm == 0) {
+      if (b.epi_pre != 0 && b.epi_pre < 4 && has_opnd && ntm == 0) {
         static VjPerDeviceOnce attrp_once;
         attrp_once([] {
           (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);

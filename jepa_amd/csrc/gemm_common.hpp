@@ -34,9 +34,10 @@ struct GemmArgs {
   const float* lnf_c;    // [N] fp32
   int dyn_slot;          // persistent kernel: >= 0 -> tiles beyond the first two rounds are handed out by per-XCD atomic counters in slot
                          // `dyn_slot` of g_pp_dyn (gemm8p.hip, option gemm_dyn); < 0 -> the static round-robin lists of rounds 3-4
-  int epi_pre = 0;       // persistent kernel, epilogues with a row operand (residual / saved gelu'): 0 -> one 16-row block ahead (rounds 3-5);
-                         // 1 -> all eight blocks requested before the epilogue's vmcnt(0), MFMA layout; 2 -> the same as sixteen full-line
-                         // 16-byte loads, re-laid-out through the staging area (option gemm_epi_pre; bit-identical results)
+  int stagger = 0;       // persistent kernel (experiment, option gemm_stagger): workgroup `pos` of an XCD sleeps (pos % 8) * stagger * 256 cycles before
+                         // its first tile, so that the epilogues of a launch's workgroups -- which otherwise start together and stay in lockstep,
+                         // 32 MB of stores and row-operand loads in one burst per tile round -- are spread over the tile period
+  int epi_pre = 0;       // persistent kernel: form of the epilogue (option gemm_epi_pre, options.hpp; gemm_epilogue_staged PRE below)
 };
 
 
@@ -237,7 +238,12 @@ struct EpiClaim {
 // anyway (64 VGPRs: the K loop's fragment registers are dead here).  2: the same bytes as sixteen row-major 16-byte loads (eight full
 // 128-byte lines per instruction instead of sixteen 32-byte pieces), parked in the staging area pass by pass and read back in the
 // MFMA layout -- the mirror image of the output path.  Same values, same arithmetic: bit-identical outputs.
-template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false, bool LNF = false, int PRE = 0>
+// NB: the launch has no bias (workgroup-uniform, resolved by the caller -- every dgrad GEMM): no bias registers (the dGELU epilogue with all its
+// row operand in flight (PRE) and sixteen column-sum accumulators is otherwise 4 VGPRs over the budget, and hipcc's spill lands between the
+// operand loads behind a vmcnt(0)) and no `+ bias` instruction (64 of a plain epilogue's ~200 vector instructions per wave tile).  Dropping
+// `+ 0.0f` keeps the bits: an accumulator that starts at +0 and is only ever added to cannot hold -0 (x + (-x) and (+0) + (-0) are +0 in
+// round-to-nearest), so there is no -0 for `+ 0.0f` to turn into +0.
+template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false, bool LNF = false, int PRE = 0, bool NB = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage,
                                                      int64_t row_lo = 0, int slot = 0, EpiClaim* ec = nullptr) {
@@ -254,13 +260,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     const int64_t n = ncol0 + j * 16;
     ncl[j] = (!EDGE || n < p.N) ? n : 0;
   }
-  float4 bias4[FN];
+  float4 bias4[NB ? 1 : FN];
+  if constexpr (!NB) {
 #pragma unroll
-  for (int j = 0; j < FN; j++) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) {
+    for (int j = 0; j < FN; j++) bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {
 #pragma unroll
-    for (int j = 0; j < FN; j++) bias4[j] = *(const float4*)(p.bias + ncl[j]);
+      for (int j = 0; j < FN; j++) bias4[j] = *(const float4*)(p.bias + ncl[j]);
+    }
   }
+  static_assert(!NB || !LNF, "no-bias variant: plain epilogues");
   static_assert(!LNF || ((EPI == EPI_BF16 || EPI == EPI_GELU) && !HAS_OPT && !CSUM), "LayerNorm fold: bf16 / GELU epilogue, no residual, no saved derivative");
   float4 lc4[LNF ? FN : 1];
   if constexpr (LNF) {
@@ -279,12 +288,18 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     }
   }
   constexpr bool HAS_OPND = (EPI == EPI_DGELU) || (EPI == EPI_BF16 && HAS_OPT);
-  static_assert(PRE == 0 || (HAS_OPND && IPP == 2 && !EDGE), "operand preload: interior tiles of the persistent kernel with a row operand");
+  // PRE 4 = PRE 3 + PIPELINED passes (see the pass loop below); also for epilogues without a row operand
+  // (PRE 5 / 6: diagnostic copies of PRE 4 for tools/gemm_stamps.py, instantiated in the stamping kernel only -- 5 issues no global store,
+  //  6 leaves out the LDS round trip and stores registers: WRONG outputs, timing only)
+  constexpr bool PIPE = PRE >= 4;
+  constexpr bool DIAG_NOST = PRE == 5, DIAG_NOLDS = PRE == 6;
+  constexpr bool PRM = HAS_OPND && (PRE == 2 || PRE == 3 || PRE >= 4);   // row operand as row-major pieces through the staging area
+  static_assert(PRE == 0 || (IPP == 2 && !EDGE && (HAS_OPND || PIPE)), "operand preload / pipelined passes: interior tiles of the persistent kernel");
   const bf16_t* opnd_p = (EPI == EPI_DGELU) ? p.aux_in : p.res;
   const int64_t opnd_ld = (EPI == EPI_DGELU) ? p.ldaux : p.ldr;
   const int rrow = lane >> 3, rch = lane & 7;   // row-major side: 8 lanes per 128-byte row, 8 rows per instruction
   u32x2_t opnd_all[PRE == 1 ? FM : 1][FN];      // PRE 1: the whole wave tile's operand in the MFMA layout
-  u32x4_t opnd_rm[PRE >= 2 ? 2 * FM : 1];       // PRE 2: ... as sixteen row-major 16-byte pieces (rows it * 8 + rrow, chunk rch)
+  u32x4_t opnd_rm[PRM ? 2 * FM : 1];            // PRE 2: ... as sixteen row-major 16-byte pieces (rows it * 8 + rrow, chunk rch)
   if constexpr (PRE == 1) {
 #pragma unroll
     for (int i = 0; i < FM; i++) {
@@ -293,19 +308,33 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
       for (int j = 0; j < FN; j++) opnd_all[i][j] = *(const u32x2_t*)(base + ncl[j]);
     }
   }
-  if constexpr (PRE >= 2) {
+  if constexpr (PRM) {
+    if constexpr (PIPE) {   // wave-uniform base (SGPRs, scalar arithmetic per row group) + one 32-bit lane offset: no vector address arithmetic
+      // (the row-group stride passes through an opaque asm: hipcc otherwise hoists the sixteen products it * stride out of the TILE loop
+      //  into SGPRs it then has to spill to vector lanes across the K loop)
+      int64_t ostep = opnd_ld * 16;   // 8 rows, bytes
+      asm volatile("" : "+s"(ostep));
+      const char* ob = (const char*)(opnd_p + m_base * opnd_ld + n_base);
+      const unsigned ooff = (unsigned)(rrow * (int)opnd_ld + rch * 8) * 2u;
 #pragma unroll
-    for (int it = 0; it < 2 * FM; it++)
-      opnd_rm[it] = *(const u32x4_t*)(opnd_p + (m_base + it * 8 + rrow) * opnd_ld + n_base + rch * 8);
+      for (int it = 0; it < 2 * FM; it++) {
+        opnd_rm[it] = *(const u32x4_t*)(ob + ooff);
+        ob += ostep;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2 * FM; it++)
+        opnd_rm[it] = *(const u32x4_t*)(opnd_p + (m_base + it * 8 + rrow) * opnd_ld + n_base + rch * 8);
+    }
   }
   if (ec != nullptr && ec->ctr != nullptr) {   // (wave-uniform) one lane claims; the wait below covers it together with the loads above
     int v = 0;
     if (lane == 0) v = __hip_atomic_fetch_add(ec->ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ec->value = __builtin_amdgcn_readfirstlane(v);
   }
-  // PRE 3: no blanket wait -- the compiler's own counted waits let pass ps start when ITS four operand loads (and the bias, and -- loads
-  // return in order -- every LDS-DMA issued before them) have landed, while the loads of the later passes are still in flight
-  if constexpr (PRE != 3) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
+  // PRE 3 / 4 with a row operand: no blanket wait -- the compiler's own counted waits let pass ps start when ITS four operand loads (and the
+  // bias, and -- loads return in order -- every LDS-DMA issued before them) have landed, while the loads of the later passes are still in flight
+  if constexpr (!(PRM && PRE >= 3)) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
 
   // LDS addresses: write (MFMA layout) and read-back (row-major) sides of the same swizzled image
   int wr_off[FN];
@@ -364,93 +393,209 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     for (int j = 0; j < FN; j++) cs01[j] = cs23[j] = (f32x2_t){0.f, 0.f};
   }
   const int row_first = (int)(row_lo - m_base) - frow;   // CSUM: block i of this lane counts iff i * 16 >= row_first
-  if constexpr (HAS_OPND && PRE == 0) load_row(0, opnd[0]);
+
+  // one element group (block i, column tile j): accumulator -> the bf16 output words `o` (and the saved derivative `dw`); `u` = this lane's
+  // 8 bytes of the row operand (residual / saved gelu'), whatever way it reached the lane
+  auto elem = [&](int i, int j, f32x2_t mk2, u32x2_t u, u32x2_t& o, u32x2_t& dw) __attribute__((always_inline)) {
+    f32x2_t v01, v23;
+    if constexpr (LNF) {   // rstd * acc + (-mean * rstd) * c[n] + b'[n]
+      const f32x2_t r2 = {lrs[i][0], lrs[i][0]}, s2 = {lrs[i][1], lrs[i][1]};
+      v01 = __builtin_elementwise_fma((f32x2_t){acc[i][j][0], acc[i][j][1]}, r2,
+                                      __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].x, lc4[j].y}, (f32x2_t){bias4[j].x, bias4[j].y}));
+      v23 = __builtin_elementwise_fma((f32x2_t){acc[i][j][2], acc[i][j][3]}, r2,
+                                      __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].z, lc4[j].w}, (f32x2_t){bias4[j].z, bias4[j].w}));
+    } else if constexpr (NB) {
+      v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]};
+      v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]};
+    } else {
+      v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
+      v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
+    }
+    if constexpr (QS) {
+      v01 *= qs2[j];
+      v23 *= qs2[j];
+    }
+    if constexpr (EPI == EPI_GELU) {
+      u32x2_t w;
+      w[0] = pack_bf2_opaque(v01[0], v01[1]);
+      w[1] = pack_bf2_opaque(v23[0], v23[1]);
+      // GELU (and, for a layer that will run backward, gelu') of the bf16-ROUNDED pre-activation
+      if constexpr (TWO_OUT) {
+        f32x2_t d01, d23;
+        if constexpr (LP) {
+          gelu_dgelu2_lp((f32x2_t){bf_lo(w[0]), bf_hi(w[0])}, v01, d01);
+          gelu_dgelu2_lp((f32x2_t){bf_lo(w[1]), bf_hi(w[1])}, v23, d23);
+        } else {
+          gelu_dgelu2((f32x2_t){bf_lo(w[0]), bf_hi(w[0])}, v01, d01);
+          gelu_dgelu2((f32x2_t){bf_lo(w[1]), bf_hi(w[1])}, v23, d23);
+        }
+        dw[0] = pack_bf2(d01[0], d01[1]);
+        dw[1] = pack_bf2(d23[0], d23[1]);
+      } else if constexpr (LP) {
+        v01 = gelu2_lp((f32x2_t){bf_lo(w[0]), bf_hi(w[0])});
+        v23 = gelu2_lp((f32x2_t){bf_lo(w[1]), bf_hi(w[1])});
+      } else {
+        v01 = gelu2((f32x2_t){bf_lo(w[0]), bf_hi(w[0])});
+        v23 = gelu2((f32x2_t){bf_lo(w[1]), bf_hi(w[1])});
+      }
+    } else if constexpr (EPI == EPI_DGELU) {
+      v01 *= (f32x2_t){bf_lo(u[0]), bf_hi(u[0])};   // u = saved gelu'(u)
+      v23 *= (f32x2_t){bf_lo(u[1]), bf_hi(u[1])};
+      if constexpr (CSUM) {
+        cs01[j] = __builtin_elementwise_fma(v01, mk2, cs01[j]);
+        cs23[j] = __builtin_elementwise_fma(v23, mk2, cs23[j]);
+      }
+    } else if constexpr (HAS_OPT) {
+      v01 += (f32x2_t){bf_lo(u[0]), bf_hi(u[0])};   // u = residual
+      v23 += (f32x2_t){bf_lo(u[1]), bf_hi(u[1])};
+    }
+    o[0] = pack_bf2(v01[0], v01[1]);
+    o[1] = pack_bf2(v23[0], v23[1]);
+  };
+  auto row_mask = [&](int i) __attribute__((always_inline)) {
+    f32x2_t mk2 = {1.f, 1.f};
+    if constexpr (CSUM) {
+      const float mk = (i * 16 >= row_first) ? 1.f : 0.f;
+      mk2 = (f32x2_t){mk, mk};
+    }
+    return mk2;
+  };
+
+  if constexpr (!PIPE) {
+    if constexpr (HAS_OPND && PRE == 0) load_row(0, opnd[0]);
 #pragma unroll
-  for (int ps = 0; ps < FM / RPP; ps++) {
-    if constexpr (PRE >= 2) {   // this pass's operand rows: registers -> the stage image at the addresses the flush reads from
+    for (int ps = 0; ps < FM / RPP; ps++) {
+      if constexpr (PRM) {   // this pass's operand rows: registers -> the stage image at the addresses the flush reads from
+#pragma unroll
+        for (int it = 0; it < RPP * 2; it++) *(u32x4_t*)(stage + it * 1024 + rd_off[it & 1]) = opnd_rm[ps * RPP * 2 + it];
+      }
+#pragma unroll
+      for (int ii = 0; ii < RPP; ii++) {
+        const int i = ps * RPP + ii;
+        if constexpr (HAS_OPND && PRE == 0) {
+          if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
+        }
+        const f32x2_t mk2 = row_mask(i);
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          u32x2_t u = {0u, 0u}, o, dw;
+          if constexpr (HAS_OPND) {
+            if constexpr (PRE == 1) u = opnd_all[i][j];
+            else if constexpr (PRM) u = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);   // (this lane overwrites the same 8 bytes below)
+            else u = opnd[i & 1][j];
+          }
+          elem(i, j, mk2, u, o, dw);
+          if constexpr (TWO_OUT) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = dw;   // the saved derivative: stage blocks 0 .. RPP-1
+          *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = o;
+        }
+      }
+      if constexpr (TWO_OUT) flush(p.aux_out, p.ldaux, ps * RPP * 16, 0);
+      flush((bf16_t*)p.C, p.ldc, ps * RPP * 16, TWO_OUT ? RPP : 0);
+    }
+  } else {
+    // PIPELINED passes (PRE 4).  The straight form above is, per wave, a chain of exposed LDS round trips: eight writes, then four times
+    // {ds_read_b128, s_waitcnt lgkmcnt(0), global_store} (hipcc keeps the source order), then the next pass's arithmetic -- sixteen serialised
+    // round trips per wave tile on an LDS that all eight waves use at once; the phase stamps (tools/gemm_stamps.py) put 2.9 ... 3.5 us of a
+    // 25 us K = 1024 tile into an epilogue whose LDS, store and vector work are ~1 us each.  Here a pass is
+    //     write O(ps) -> issue the four row-major reads V(ps) -> [park the operand rows of pass ps + 1, read them back in the MFMA layout]
+    //     -> the arithmetic of pass ps + 1 into registers O(ps + 1), under the reads' latency -> store V(ps)
+    // (LDS operations of a wave execute in order, so overwriting the image behind the issued reads is safe.)  Same values, same arithmetic:
+    // bit-identical outputs.
+    constexpr int NP = FM / RPP;
+    constexpr int NV = TWO_OUT ? 4 * RPP : 2 * RPP;
+    u32x2_t O[RPP][FN], Dw[TWO_OUT ? RPP : 1][FN];
+    auto park = [&](int ps) __attribute__((always_inline)) {
 #pragma unroll
       for (int it = 0; it < RPP * 2; it++) *(u32x4_t*)(stage + it * 1024 + rd_off[it & 1]) = opnd_rm[ps * RPP * 2 + it];
-    }
+    };
+    auto compute = [&](int ps) __attribute__((always_inline)) {
+      u32x2_t U[RPP][FN];
+#pragma unroll
+      for (int ii = 0; ii < RPP; ii++)
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          if constexpr (PRM) U[ii][j] = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);
+          else U[ii][j] = (u32x2_t){0u, 0u};
+        }
+#pragma unroll
+      for (int ii = 0; ii < RPP; ii++) {
+        const int i = ps * RPP + ii;
+        const f32x2_t mk2 = row_mask(i);
+#pragma unroll
+        for (int j = 0; j < FN; j++) {
+          u32x2_t dw;
+          elem(i, j, mk2, U[ii][j], O[ii][j], dw);
+          if constexpr (TWO_OUT) Dw[ii][j] = dw;
+        }
+      }
+    };
+    // pass 0 in the straight form (element by element into the stage: with all 128 accumulators and the whole row operand still live there
+    // are no registers for a pass of outputs)
+    if constexpr (PRM) park(0);
 #pragma unroll
     for (int ii = 0; ii < RPP; ii++) {
-      const int i = ps * RPP + ii;
-      if constexpr (HAS_OPND && PRE == 0) {
-        if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
-      }
-      f32x2_t mk2 = {1.f, 1.f};
-      if constexpr (CSUM) {
-        const float mk = (i * 16 >= row_first) ? 1.f : 0.f;
-        mk2 = (f32x2_t){mk, mk};
-      }
+      const f32x2_t mk2 = row_mask(ii);
 #pragma unroll
       for (int j = 0; j < FN; j++) {
-        f32x2_t v01, v23;
-        if constexpr (LNF) {   // rstd * acc + (-mean * rstd) * c[n] + b'[n]
-          const f32x2_t r2 = {lrs[i][0], lrs[i][0]}, s2 = {lrs[i][1], lrs[i][1]};
-          v01 = __builtin_elementwise_fma((f32x2_t){acc[i][j][0], acc[i][j][1]}, r2,
-                                          __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].x, lc4[j].y}, (f32x2_t){bias4[j].x, bias4[j].y}));
-          v23 = __builtin_elementwise_fma((f32x2_t){acc[i][j][2], acc[i][j][3]}, r2,
-                                          __builtin_elementwise_fma(s2, (f32x2_t){lc4[j].z, lc4[j].w}, (f32x2_t){bias4[j].z, bias4[j].w}));
+        u32x2_t u = {0u, 0u}, o, dw;
+        if constexpr (PRM) u = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);
+        elem(ii, j, mk2, u, o, dw);
+        if constexpr (DIAG_NOLDS) {
+          O[ii][j] = o;
         } else {
-          v01 = (f32x2_t){acc[i][j][0], acc[i][j][1]} + (f32x2_t){bias4[j].x, bias4[j].y};   // v_pk_add_f32
-          v23 = (f32x2_t){acc[i][j][2], acc[i][j][3]} + (f32x2_t){bias4[j].z, bias4[j].w};
+          if constexpr (TWO_OUT) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = dw;
+          *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = o;
         }
-        if constexpr (QS) {
-          v01 *= qs2[j];
-          v23 *= qs2[j];
-        }
-        u32x2_t o;
-        if constexpr (EPI == EPI_GELU) {
-          u32x2_t u;
-          u[0] = pack_bf2_opaque(v01[0], v01[1]);
-          u[1] = pack_bf2_opaque(v23[0], v23[1]);
-          // GELU (and, for a layer that will run backward, gelu') of the bf16-ROUNDED pre-activation
-          if constexpr (TWO_OUT) {
-            f32x2_t d01, d23;
-            if constexpr (LP) {
-              gelu_dgelu2_lp((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
-              gelu_dgelu2_lp((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
-            } else {
-              gelu_dgelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])}, v01, d01);
-              gelu_dgelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])}, v23, d23);
-            }
-            u32x2_t dw;
-            dw[0] = pack_bf2(d01[0], d01[1]);
-            dw[1] = pack_bf2(d23[0], d23[1]);
-            *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = dw;   // the saved derivative: stage blocks 0 .. RPP-1
-          } else if constexpr (LP) {
-            v01 = gelu2_lp((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
-            v23 = gelu2_lp((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
-          } else {
-            v01 = gelu2((f32x2_t){bf_lo(u[0]), bf_hi(u[0])});
-            v23 = gelu2((f32x2_t){bf_lo(u[1]), bf_hi(u[1])});
-          }
-        } else if constexpr (EPI == EPI_DGELU) {
-          u32x2_t u;   // saved gelu'(u)
-          if constexpr (PRE == 1) u = opnd_all[i][j];
-          else if constexpr (PRE >= 2) u = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);   // (this lane overwrites the same 8 bytes below)
-          else u = opnd[i & 1][j];
-          v01 *= (f32x2_t){bf_lo(u[0]), bf_hi(u[0])};
-          v23 *= (f32x2_t){bf_lo(u[1]), bf_hi(u[1])};
-          if constexpr (CSUM) {
-            cs01[j] = __builtin_elementwise_fma(v01, mk2, cs01[j]);
-            cs23[j] = __builtin_elementwise_fma(v23, mk2, cs23[j]);
-          }
-        } else if constexpr (HAS_OPT) {
-          u32x2_t r2;
-          if constexpr (PRE == 1) r2 = opnd_all[i][j];
-          else if constexpr (PRE >= 2) r2 = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);
-          else r2 = opnd[i & 1][j];
-          v01 += (f32x2_t){bf_lo(r2[0]), bf_hi(r2[0])};
-          v23 += (f32x2_t){bf_lo(r2[1]), bf_hi(r2[1])};
-        }
-        o[0] = pack_bf2(v01[0], v01[1]);
-        o[1] = pack_bf2(v23[0], v23[1]);
-        *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = o;
       }
     }
-    if constexpr (TWO_OUT) flush(p.aux_out, p.ldaux, ps * RPP * 16, 0);
-    flush((bf16_t*)p.C, p.ldc, ps * RPP * 16, TWO_OUT ? RPP : 0);
+    // output row-group pointers / strides (the strides pass through an opaque asm: hipcc otherwise turns the running pointer back into
+    // sixteen products it * stride, hoists them out of the TILE loop and spills the SGPRs to vector lanes across the K loop)
+    int64_t step_c = p.ldc * 16, step_aux = TWO_OUT ? p.ldaux * 16 : 0;   // 8 rows, bytes
+    asm volatile("" : "+s"(step_c));
+    if constexpr (TWO_OUT) asm volatile("" : "+s"(step_aux));
+    char* ob_c = (char*)((bf16_t*)p.C + m_base * p.ldc + n_base);
+    char* ob_aux = TWO_OUT ? (char*)(p.aux_out + m_base * p.ldaux + n_base) : nullptr;
+    const unsigned ooff_c = (unsigned)(rrow * (int)p.ldc + rch * 8) * 2u;
+    const unsigned ooff_aux = TWO_OUT ? (unsigned)(rrow * (int)p.ldaux + rch * 8) * 2u : 0u;
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+      u32x4_t V[NV];
+#pragma unroll
+      for (int it = 0; it < NV; it++) {
+        if constexpr (DIAG_NOLDS) V[it] = (u32x4_t){O[it % RPP][it % FN][0], O[it % RPP][it % FN][1], O[(it + 1) % RPP][(it + 2) % FN][0], O[(it + 1) % RPP][(it + 2) % FN][1]};
+        else V[it] = *(const u32x4_t*)(stage + it * 1024 + rd_off[it & 1]);   // (two outputs: the derivative's blocks first)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ps + 1 < NP) {
+        if constexpr (PRM) park(ps + 1);
+        compute(ps + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < NV; it++) {
+        const bool second = TWO_OUT && it >= 2 * RPP;                  // two outputs: V[0 .. 2 RPP) -> aux_out, the rest -> C
+        // wave-uniform row-group pointer (advanced by scalar adds) + one 32-bit lane offset: global_store ... s[base] form.  The vector
+        // form cost 47 of the ~300 instructions of a plain epilogue, whose time is the issue of its instructions (tools/gemm_stamps.py)
+        char*& ob = (TWO_OUT && !second) ? ob_aux : ob_c;
+        const unsigned ooff = (TWO_OUT && !second) ? ooff_aux : ooff_c;
+        if constexpr (DIAG_NOST) {
+          asm volatile("" ::"v"(V[it]));   // the read-back still happens and is waited for
+          if (p.M < 0) *(u32x4_t*)(ob + ooff) = V[it];
+        } else {
+          *(u32x4_t*)(ob + ooff) = V[it];
+        }
+        ob += (TWO_OUT && !second) ? step_aux : step_c;
+      }
+      if (ps + 1 < NP && !DIAG_NOLDS) {
+#pragma unroll
+        for (int ii = 0; ii < RPP; ii++)
+#pragma unroll
+          for (int j = 0; j < FN; j++) {
+            if constexpr (TWO_OUT) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = Dw[ii][j];
+            *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = O[ii][j];
+          }
+      }
+    }
   }
   if constexpr (CSUM) {
     // sum over the 16 rows (lanes frow = 0..15 of each 16-lane DPP row hold the same columns): rotate-and-add, fixed order
@@ -464,8 +609,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
 #pragma unroll
       for (int c = 0; c < 4; c++) cv[j][c] = row16_sum(cv[j][c]);
     }
-    if (frow == 0) {
-      float* cp = p.colpart + (int64_t)slot * p.N + n_base + fg * 4;
+    // (lane id re-derived through a volatile asm: the per-lane address below is then computed HERE, not hoisted to the top of the epilogue,
+    //  where it would be one 64-bit value too many next to 128 accumulators + 64 operand registers + 16 sums -- hipcc spilled it, and the
+    //  reload's wait behind the epilogue's stores drained them)
+    int l2;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+    if ((l2 & 15) == 0) {
+      float* cp = p.colpart + (int64_t)slot * p.N + n_base + (l2 >> 4) * 4;
 #pragma unroll
       for (int j = 0; j < FN; j++) *(float4*)(cp + j * 16) = make_float4(cv[j][0], cv[j][1], cv[j][2], cv[j][3]);
     }
@@ -491,17 +641,29 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     else if constexpr (EPI == EPI_BF16) opt = p.res != nullptr;
     else opt = true;
     const bool edge = __builtin_amdgcn_readfirstlane((m_base + 128 > p.M) || (n_base + 64 > p.N));
+    constexpr int XP = (PRE >= 4 && IPP == 2) ? PRE : 0;   // pipelined passes: every interior variant of the persistent kernel
     if constexpr (EPI == EPI_DGELU && IPP == 2) {   // persistent kernel (every tile interior): optional fused column sums
       if (p.colpart != nullptr && !edge) {
-        gemm_epilogue_staged<EPI, true, false, IPP, true, false, false, false, PRE>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
+        if constexpr (PRE != 0) {   // (a dgrad GEMM has no bias; with one, the kernel that keeps bias registers)
+          if (p.bias == nullptr) gemm_epilogue_staged<EPI, true, false, IPP, true, false, false, false, PRE, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
+          else gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
+        } else {
+          gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
+        }
         return true;
       }
     }
     // row operand requested up front (option gemm_epi_pre -> a kernel of its own: the variant is a compile-time property, so that the
     // default kernels' register allocation is untouched)
     if constexpr (PRE != 0 && (EPI == EPI_DGELU || EPI == EPI_BF16) && IPP == 2) {
-      if (opt && !edge && (EPI == EPI_DGELU || p.lnf_rs == nullptr)) {
-        gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, PRE>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+      if (opt && !edge && (EPI == EPI_DGELU ? p.bias == nullptr : p.lnf_rs == nullptr)) {
+        if constexpr (EPI == EPI_BF16 && PRE >= 4) {   // (pipelined form: a residual GEMM without a bias -- the dgrad that adds the skip path's gradient)
+          if (p.bias == nullptr) {
+            gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, PRE, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            return true;
+          }
+        }
+        gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, PRE, EPI == EPI_DGELU>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
         return true;
       }
     }
@@ -510,18 +672,18 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
         if constexpr (EPI == EPI_BF16) {
           if (p.qscale != 0.f && n_base < p.qcols) {
             if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
           } else {
             if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
           }
         } else {
           if (p.gelu_lp) {
             if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
           } else {
             if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
           }
         }
         return true;
@@ -530,7 +692,7 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     if constexpr (EPI == EPI_BF16) {
       if (p.qscale != 0.f && n_base < p.qcols) {   // wave tiles that hold q columns only (the launcher guarantees: no residual)
         if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-        else gemm_epilogue_staged<EPI, false, false, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+        else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
         return true;
       }
     }
@@ -538,20 +700,29 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
       if (p.gelu_lp) {   // workgroup-uniform (kernel argument)
         if (opt) {
           if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-          else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+          else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
         } else {
           if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
         }
         return true;
       }
     }
     if (opt) {
       if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-      else gemm_epilogue_staged<EPI, true, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+      else gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, EPI == EPI_DGELU ? 0 : XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);   // (dGELU WITH a bias: the straight form)
     } else if constexpr (EPI != EPI_DGELU) {
-      if (edge) gemm_epilogue_staged<EPI, false, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-      else gemm_epilogue_staged<EPI, false, false, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+      if (edge) {
+        gemm_epilogue_staged<EPI, false, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+      } else {
+        if constexpr (EPI == EPI_BF16 && XP >= 4) {   // (pipelined form: plain dgrad GEMMs have no bias)
+          if (p.bias == nullptr) {
+            gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, false, XP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            return true;
+          }
+        }
+        gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+      }
     }
     return true;
   }

@@ -24,7 +24,7 @@ enum VjOpt {
                                // 0: one launch each (different fp32 summation order: results agree to rounding, not bitwise)
   VJ_OPT_WGRAD_SLOW_ISSUE,     // 1: the TN kernel's K loop issues its parts through the generic address path (A/B only)
   VJ_OPT_ATTN_DKDV_KT,         // 16-key tiles per wave in the attention dK/dV kernel: 0 (default) per head-dim class, 1 / 2 forced, 4 (round 5) at head_dim <= 32
-  VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores)
+  VJ_OPT_GEMM_DBG,             // diagnostics of the GEMM kernels (bit0 drop the epilogue, bit1 unstaged stores, bit2 phase stamps of the persistent kernel: tools/gemm_stamps.py)
   VJ_OPT_ATTN_SOFTMAX,         // 1 (A/B only): attention kernels with the soft-max scale folded into the stationary operand
                                // and the score accumulators seeded with -max / -lse (no per-score FMA, no per-tile row maximum).  With a
                                // positive scale the forward / dQ kernels fold c into Q and dK/dV folds it into K: the backward's scores
@@ -64,9 +64,12 @@ enum VjOpt {
                                // range-wise update running beside the next step's forward (Trainer(overlap_update)).  Same results
   VJ_OPT_WS_GUARD,             // diagnostics: 1 = 256-byte guard gaps behind every member of the chain workspaces, poisoned by the chain calls and
                                // inspected by vj_ws_guard_check (tests/test_round5_gpu.py).  Changes the workspace sizes: set it before the first step
-  VJ_OPT_GEMM_EPI_PRE,         // persistent NT GEMM, epilogues with a row operand (residual add, dGELU): 0 = the operand's 16-row blocks are requested one
-                               // block ahead; 1 = all eight before the epilogue's single vmcnt(0) (MFMA layout); 2 = as sixteen full-line 16-byte loads
-                               // re-laid-out through the staging area (gemm_common.hpp gemm_epilogue_staged PRE).  Bit-identical results
+  VJ_OPT_GEMM_EPI_PRE,         // persistent NT GEMM, form of the epilogue (gemm_common.hpp gemm_epilogue_staged PRE; all bit-identical): 0 = straight passes, a row
+                               // operand (residual, saved gelu') requested one 16-row block ahead; 1 = all eight blocks before the epilogue's single vmcnt(0)
+                               // (MFMA layout); 2 = as sixteen full-line 16-byte loads re-laid-out through the staging area; 3 = 2 without the blanket
+                               // wait; 4 (default) = 3 + software-pipelined passes, scalar row pointers, no-bias variants, for EVERY epilogue;
+                               // 5 / 6 = diagnostic copies of 4 inside the phase-stamping kernel only (no stores / no LDS round trip: wrong outputs)
+  VJ_OPT_GEMM_STAGGER,         // persistent NT GEMM (experiment): workgroup pos of an XCD sleeps (pos % 8) * value * 256 cycles before its first tile
   VJ_OPT_COUNT
 };
 

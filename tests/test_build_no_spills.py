@@ -28,6 +28,8 @@ def test_no_kernel_spills_vector_registers():
     for base, text in outs:
         for name, spill in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
             n_kernels += 1
+            if "stamp_kernel" in name:   # diagnostic copies of the persistent GEMM (gemm_dbg = 4, tools/gemm_stamps.py): not on the product path
+                continue
             if int(spill) != 0:
                 offenders.append((base, name, int(spill)))
     assert n_kernels >= 100, n_kernels          # 106 kernels at the end of round 3

@@ -522,7 +522,7 @@ def test_non_temporal_operand_hint_is_bit_identical(ops, M, N, K):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("M,N,K", [(37632, 1024, 256), (5000, 1288, 256), (10560, 1024, 1088), (2304 + 40, 2600, 320), (58560, 384, 384)])
 def test_epilogue_operand_preload_is_bit_identical(ops, M, N, K):
-    """Option gemm_epi_pre = 1 / 2: the residual (EPI_BF16) / the saved gelu' (EPI_DGELU, with and without fused column sums) of a wave
+    """Option gemm_epi_pre = 1 / 2 / 3 (2 is the default): the residual (EPI_BF16) / the saved gelu' (EPI_DGELU, with and without fused column sums) of a wave
     tile is requested in one go before the epilogue's vmcnt(0) -- in the MFMA layout (1) or as full-line 16-byte loads re-laid-out
     through the staging area (2) -- instead of one 16-row block ahead.  Same values into the same arithmetic: the bits of the default,
     also on shifted edge tiles, with the dynamic tile hand-out and with the full grid; launches without a row operand keep their kernel."""
@@ -544,10 +544,64 @@ def test_epilogue_operand_preload_is_bit_identical(ops, M, N, K):
         return outs
     with _opt("gemm_epi_pre", 0):
         ref = run_all()
-    for pre in (1, 2):
+    for pre in (1, 2, 3):
         for persist, dyn in ((1, 0), (2, 0), (1, 1)):
             with _opt("gemm_epi_pre", pre), _opt("gemm_persist", persist), _opt("gemm_dyn", dyn):
                 for rep in range(2):
                     got = run_all()
                     for i, (a, b) in enumerate(zip(ref, got)):
                         assert torch.equal(a, b), (pre, persist, dyn, rep, i, int((a != b).sum()))
+
+
+# ------------------------------------------------------------------------------------------ pipelined epilogue passes
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("M,N,K", [(37632, 1152, 256), (5000, 1296, 256), (10560, 1536, 1088), (2304 + 40, 2592, 320), (58560, 384, 384)])
+def test_pipelined_epilogue_is_bit_identical(ops, M, N, K):
+    """Option gemm_epi_pre = 4: the persistent kernel's epilogue passes are software-pipelined (the row-major read-back of pass ps is in
+    flight while the arithmetic of pass ps + 1 runs; a row operand is parked and re-read for the next pass behind the issued reads).
+    Every epilogue the persistent kernel has -- plain / bias / residual, the q-column scale, GELU with one and two outputs (both GELU
+    forms), dGELU with and without the fused column sums, the folded LayerNorm -- must give the bits of the straight form (option 0),
+    also on shifted edge tiles, with the full grid and with the dynamic tile hand-out."""
+    g = torch.Generator(device=DEV).manual_seed(67)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    aux = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(torch.bfloat16)
+    Wf32 = torch.randn(N, K, device=DEV, generator=g) * 0.05
+    gamma = 1.0 + 0.3 * torch.randn(K, device=DEV, generator=g)
+    beta = 0.2 * torch.randn(K, device=DEV, generator=g)
+    rs = ops.ln_rowstats(A, 1e-6)
+    Wf, cvec, bfold = ops.ln_fold_weights(Wf32, bias, gamma, beta)
+    qs = 0.125 * 1.4426950408889634
+
+    def run_all():
+        outs = [ops.gemm_nt(A, W), ops.gemm_nt(A, W, bias=bias), ops.gemm_nt(A, W, bias=bias, residual=res), ops.gemm_nt(A, W, residual=res)]
+        if N % 12 == 0:
+            outs.append(ops.gemm_nt(A, W, bias=bias, epilogue=ops.EPI_QKV, alpha=qs))
+            outs.append(ops.gemm_nt_lnfold(A, Wf, bfold, rs, cvec, epilogue=ops.EPI_QKV, alpha=qs))
+        for poly in (1, 0):
+            with _opt("gelu_poly", poly):
+                outs.append(ops.gemm_nt(A, W, bias=bias, epilogue=ops.EPI_GELU))
+                d = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+                outs.append(ops.gemm_nt(A, W, bias=bias, aux_out=d, epilogue=ops.EPI_GELU))
+                outs.append(d)
+                outs.append(ops.gemm_nt_lnfold(A, Wf, bfold, rs, cvec, epilogue=ops.EPI_GELU))
+        outs.append(ops.gemm_nt_lnfold(A, Wf, bfold, rs, cvec))
+        du, colpart = ops.gemm_dgelu_colsum(A, W, aux)
+        outs.append(du)
+        if colpart is not None:
+            outs.append(colpart)
+        outs.append(ops.gemm_nt(A, W, aux_in=aux, epilogue=ops.EPI_DGELU))
+        outs.append(ops.gemm_nt(A, W, bias=bias, aux_in=aux, epilogue=ops.EPI_DGELU))
+        torch.cuda.synchronize()
+        return outs
+    with _opt("gemm_epi_pre", 0):
+        ref = run_all()
+    for persist, dyn in ((1, 0), (2, 0), (1, 1)):
+        with _opt("gemm_epi_pre", 4), _opt("gemm_persist", persist), _opt("gemm_dyn", dyn):
+            for rep in range(2):
+                got = run_all()
+                assert len(got) == len(ref)
+                for i, (a, b) in enumerate(zip(ref, got)):
+                    assert torch.equal(a, b), (persist, dyn, rep, i, int((a != b).sum()))
