@@ -557,20 +557,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     char* ob_aux = TWO_OUT ? (char*)(p.aux_out + m_base * p.ldaux + n_base) : nullptr;
     const unsigned ooff_c = (unsigned)(rrow * (int)p.ldc + rch * 8) * 2u;
     const unsigned ooff_aux = TWO_OUT ? (unsigned)(rrow * (int)p.ldaux + rch * 8) * 2u : 0u;
-#pragma unroll
-    for (int ps = 0; ps < NP; ps++) {
-      u32x4_t V[NV];
+    auto read_back = [&](u32x4_t (&V)[NV]) __attribute__((always_inline)) {
 #pragma unroll
       for (int it = 0; it < NV; it++) {
         if constexpr (DIAG_NOLDS) V[it] = (u32x4_t){O[it % RPP][it % FN][0], O[it % RPP][it % FN][1], O[(it + 1) % RPP][(it + 2) % FN][0], O[(it + 1) % RPP][(it + 2) % FN][1]};
         else V[it] = *(const u32x4_t*)(stage + it * 1024 + rd_off[it & 1]);   // (two outputs: the derivative's blocks first)
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (ps + 1 < NP) {
-        if constexpr (PRM) park(ps + 1);
-        compute(ps + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto store_out = [&](const u32x4_t (&V)[NV]) __attribute__((always_inline)) {
 #pragma unroll
       for (int it = 0; it < NV; it++) {
         const bool second = TWO_OUT && it >= 2 * RPP;                  // two outputs: V[0 .. 2 RPP) -> aux_out, the rest -> C
@@ -586,7 +580,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
         }
         ob += (TWO_OUT && !second) ? step_aux : step_c;
       }
-      if (ps + 1 < NP && !DIAG_NOLDS) {
+    };
+    auto put = [&]() __attribute__((always_inline)) {   // O (and Dw) -> the stage image
+      if constexpr (!DIAG_NOLDS) {
 #pragma unroll
         for (int ii = 0; ii < RPP; ii++)
 #pragma unroll
@@ -595,7 +591,22 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
             *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = O[ii][j];
           }
       }
+    };
+#pragma unroll
+    for (int ps = 0; ps < NP; ps++) {
+      u32x4_t V[NV];
+      read_back(V);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ps + 1 < NP) {
+        if constexpr (PRM) park(ps + 1);
+        compute(ps + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      store_out(V);
+      if (ps + 1 < NP) put();
     }
+    // (one pass deeper -- the image of pass ps + 1 written and its read-back issued before the stores of pass ps -- was built and measured
+    //  level: profiles/r05_epi_pipeline.md)
   }
   if constexpr (CSUM) {
     // sum over the 16 rows (lanes frow = 0..15 of each 16-lane DPP row hold the same columns): rotate-and-add, fixed order
