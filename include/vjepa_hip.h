@@ -376,7 +376,7 @@ int vj_comm_destroy(vj_comm_t comm);
  * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
  * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_tn",
  * "wgrad_group", "wgrad_slow_issue", "attn_dkdv_kt", "gemm_dbg", "attn_softmax", "bias_fuse", "gelu_poly", "gemm_sched", "attn_psum",
- * "attn_merge", "ln_bwd_prefetch", "gemm_raster", "attn_dq_qw", "gemm_nt", "gemm_dyn", "adam_grid", "ws_guard", "gemm_epi_pre", "gemm_stagger" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * "attn_merge", "ln_bwd_prefetch", "gemm_raster", "attn_dq_qw", "gemm_nt", "gemm_dyn", "adam_grid", "ws_guard", "gemm_epi_pre" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
  * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
 int vj_set_option(const char* name, int value);
 int vj_get_option(const char* name, int* value);

@@ -165,10 +165,6 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     return;
   }
 
-  if (p.stagger != 0) {   // (workgroup-uniform) option gemm_stagger: de-synchronise the launch's workgroups
-    const int n = (pos & 7) * p.stagger;
-    for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(4);
-  }
   const int nk = (int)(p.K / 64);
   const int64_t lda2 = p.lda * 2, ldb2 = p.ldb * 2;
   // per-thread byte offsets of a part's chunks (see gemm8.hip): row r0 (+ 64 j), chunk column swizzled by the row
@@ -582,7 +578,6 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   b.dyn_slot = (vj_opt(VJ_OPT_GEMM_DYN) != 0 && vj_opt(VJ_OPT_GEMM_SCHED) == 4 && !(a.dbg & 1))
                    ? (int)(dyn_seq.fetch_add(1, std::memory_order_relaxed) % PP_DYN_SLOTS) : -1;
   b.epi_pre = vj_opt(VJ_OPT_GEMM_EPI_PRE);
-  b.stagger = vj_opt(VJ_OPT_GEMM_STAGGER);
   if (b.raster == 511) {   // automatic: column groups of six for the encoder shapes (K >= 1024), the row-grouped order for the short-K predictor shapes
     b.raster = a.K >= 1024 ? 256 + 6 : 0;
   }

@@ -34,9 +34,6 @@ struct GemmArgs {
   const float* lnf_c;    // [N] fp32
   int dyn_slot;          // persistent kernel: >= 0 -> tiles beyond the first two rounds are handed out by per-XCD atomic counters in slot
                          // `dyn_slot` of g_pp_dyn (gemm8p.hip, option gemm_dyn); < 0 -> the static round-robin lists of rounds 3-4
-  int stagger = 0;       // persistent kernel (experiment, option gemm_stagger): workgroup `pos` of an XCD sleeps (pos % 8) * stagger * 256 cycles before
-                         // its first tile, so that the epilogues of a launch's workgroups -- which otherwise start together and stay in lockstep,
-                         // 32 MB of stores and row-operand loads in one burst per tile round -- are spread over the tile period
   int epi_pre = 0;       // persistent kernel: form of the epilogue (option gemm_epi_pre, options.hpp; gemm_epilogue_staged PRE below)
 };
 

@@ -26,7 +26,7 @@ const OptDef kDefs[VJ_OPT_COUNT] = {
     {"attn_softmax", 2, 0, 2},        {"bias_fuse", 1, 0, 1},             {"gelu_poly", 1, 0, 1},
     {"gemm_sched", 4, 4, 8},          {"attn_psum", 1, 0, 1},            {"attn_merge", 1, 0, 1},
     {"ln_bwd_prefetch", 1, 0, 1},  {"gemm_raster", 260, 0, 511},  {"attn_dq_qw", 0, 0, 4}, {"gemm_nt", 0, 0, 2}, {"gemm_dyn", 0, 0, 1}, {"adam_grid", 0, 0, 4096}, {"ws_guard", 0, 0, 1},
-    {"gemm_epi_pre", 4, 0, 6}, {"gemm_stagger", 0, 0, 64},
+    {"gemm_epi_pre", 4, 0, 6},
 };
 std::atomic<int> g_val[VJ_OPT_COUNT];
 std::once_flag g_once;

@@ -69,7 +69,6 @@ enum VjOpt {
                                // (MFMA layout); 2 = as sixteen full-line 16-byte loads re-laid-out through the staging area; 3 = 2 without the blanket
                                // wait; 4 (default) = 3 + software-pipelined passes, scalar row pointers, no-bias variants, for EVERY epilogue;
                                // 5 / 6 = diagnostic copies of 4 inside the phase-stamping kernel only (no stores / no LDS round trip: wrong outputs)
-  VJ_OPT_GEMM_STAGGER,         // persistent NT GEMM (experiment): workgroup pos of an XCD sleeps (pos % 8) * value * 256 cycles before its first tile
   VJ_OPT_COUNT
 };
 

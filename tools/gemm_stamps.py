@@ -88,7 +88,7 @@ def main():
         ("prd fc2", 58368, 384, 1536, ("bias+res",)),
         ("prd dfc2", 58368, 1536, 384, ("dgelu",)),
     ]
-    # arguments: comma-separated gemm_epi_pre values, then any number of option settings "name=value" (e.g. gemm_stagger=8 gemm_dyn=1),
+    # arguments: comma-separated gemm_epi_pre values, then any number of option settings "name=value" (e.g. gemm_dyn=1 gemm_persist=2),
     # then optionally "only=<tag substring>"
     pres = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2"])]
     only = None
