@@ -438,7 +438,8 @@ def main():
         csv_path = args.gemm_csv or os.path.join(tempfile.gettempdir(), f"vj_bench_launches_{os.getpid()}.csv")
         fam = chain.prof_collect(csv_path)
         # per-epilogue split of the C chains' GEMM launches (csv: family,tag,m,n,k,us; family 0 = GEMM, tag 0 = bf16 epilogue
-        # with optional bias / residual = gemm_nt_4phase_persist_kernel<0>, the kernel with the largest share of the step)
+        # with optional bias / residual = gemm_nt_4phase_persist_pre_kernel<0, 4> (round 5: the persistent kernel with the pipelined epilogue),
+        # the kernel with the largest share of the step)
         dom = dict(launches=0, ms=0.0, flop=0.0, bytes=0.0)
         with open(csv_path) as fcsv:
             next(fcsv)
@@ -462,14 +463,14 @@ def main():
         log(f"roofline pass: {json.dumps({k: dict(v, tflops=round(v['flop'] / v['ms'] / 1e9, 1)) for k, v in fam.items()})}")
         # HBM bytes per launch of the dominant kernel: measured with rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
         # correction + WRITE_SIZE), committed under profiles/ -- counters cannot be collected from inside this process
-        DOM = "gemm_nt_4phase_persist_kernel<0>"
+        DOM = "gemm_nt_4phase_persist_pre_kernel<0, 4>"
         traffic, traffic_src = None, None
         for pmc_name in ("r05_hbm_pmc.json", "r04_hbm_pmc.json"):   # newest first (round 5: taken at HEAD with the column-grouped tile order)
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and args.workload == "vitl16":
                 with open(pmc) as fjs:
                     tab = json.load(fjs)
-                ent = tab.get(DOM) or tab.get("gemm_nt_4phase_persist_kernel<0, 0>")   # (a second template argument since round 5)
+                ent = tab.get(DOM) or tab.get("gemm_nt_4phase_persist_kernel<0, 0>") or tab.get("gemm_nt_4phase_persist_kernel<0>")   # (older tables: the same kernel before its epilogue was pipelined)
                 if ent:
                     traffic, traffic_src = round(ent["hbm_bytes_per_launch"]), "profiles/" + pmc_name
                     break
@@ -483,8 +484,8 @@ def main():
                 "achieved": whole["achieved"], "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": whole["frac"],
                 "traffic": traffic, "traffic_unit": f"HBM bytes per launch of {DOM} (PMC)", "traffic_source": traffic_src,
                 "whole_step": whole,
-                "gemm_family": {"kernels": "gemm_nt_4phase_persist_kernel<0|1|2> (persistent 256x256 NT, two staggered wave groups, two "
-                                           "32-MFMA sections per K-tile, cross-tile LDS-DMA prefetch), gemm_tn_8phase_kernel "
+                "gemm_family": {"kernels": "gemm_nt_4phase_persist_pre_kernel<0|1|2, 4> (persistent 256x256 NT, two staggered wave groups, two "
+                                           "32-MFMA sections per K-tile, cross-tile LDS-DMA prefetch, pipelined epilogue), gemm_tn_8phase_kernel "
                                            "(transpose-free weight gradients, the four of a block in one launch); MFMA 16x16x32 bf16",
                                 "achieved": round(ach / 1e12, 2), "frac": round(ach / MFMA_BF16_PEAK, 4),
                                 "launches_per_step": g["launches"] // n_inst,
