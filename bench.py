@@ -356,7 +356,10 @@ def main():
             log(f"exposed communication (compute stream blocked in reducer.finish): {ex:.2f} ms/step over the last "
                 f"{trainer.reducer.exposed_samples} steps")
             ex = max_over_ranks(ex, world, device)
-        dp_info = {"ranks": world, "backend": "rccl via torch.distributed",
+        from jepa_amd.engine import layers as _layers
+        log(f"collectives issued {trainer.reducer.coll_mode!r}; stream picks (candidate index, concurrent with each stream it must not share a "
+            f"hardware queue with): {_layers._INDEP_LOG}")
+        dp_info = {"ranks": world, "backend": "rccl via the C ABI (vj_comm_*)" if trainer.reducer.coll_mode == "capi" else "rccl via torch.distributed", "collectives": trainer.reducer.coll_mode,
                    "layer_buckets": len(trainer.reducer.buckets), "tail_ranges": len(trainer.reducer.tail),
                    "grad_bytes_per_step": int(trainer.arena.total * 4),
                    "exposed_comm_ms_per_step": None if ex is None else round(ex, 3),

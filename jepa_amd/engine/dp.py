@@ -12,11 +12,16 @@ mean inside the fused AdamW kernel (gscale = 1/world), so no extra pass touches 
 With world_size == 1 every method is a no-op.  On CPU tensors (gloo, used by the tests) the same bucket walk
 runs synchronously.
 
-Collective contract: torch.distributed's process group (backend "nccl" IS RCCL on ROCm; it is the group the launcher already
-created).  The library also binds RCCL behind the C ABI (`vj_comm_*`, include/vjepa_hip.h) for hosts that do not run
-torch.distributed; this reducer does not use it: driven from here at one rank it made the step 17 % slower in rounds 3 and 4
-(91.0 vs 75.9 ms; the kernel trace shows no RCCL kernel, only inflated compute-kernel durations -- profiles/r04_dp1_capi_trace.md),
-so the switch that selected it (VJ_COMM_BACKEND) was removed in round 4.
+Collectives (VJ_DP_COLL): every bucket's all-reduce is issued ON the engine's own communication stream -- a stream that was tested
+for sharing a hardware queue with none of the compute streams (engine/layers.py independent_stream):
+  "sync"  (default) torch.distributed's process group (backend "nccl" IS RCCL on ROCm; the group the launcher created), called with
+          async_op=False inside the stream's context: ProcessGroupNCCL then launches on that stream;
+  "capi"  the library's own RCCL binding (`vj_comm_*`, include/vjepa_hip.h: what a host without torch.distributed calls); the 128-byte
+          unique id travels over the existing process group once, at construction;
+  "async" round 2-4's form, async_op=True: ProcessGroupNCCL launches on a pooled stream of ITS OWN.  When that stream shares a hardware
+          queue with a compute stream its event waits stall that stream's kernels: 86.6 - 87.2 ms per step against 71.3 at one rank,
+          3 of 3 processes (profiles/r05_dp1_coll_mode.md) -- the signature of the "unexplained" 17 % of the capi route in rounds 3 / 4,
+          whose communication stream was simply never checked (profiles/r04_dp1_capi_trace.md, r05_queue_aliasing.md).  Kept as the A/B control.
 """
 import torch
 import torch.distributed as dist
@@ -31,6 +36,16 @@ class GradReducer:
         self.enabled = world_size > 1 or (os.environ.get("VJ_FORCE_DP", "0") == "1" and dist.is_available()
                                           and dist.is_initialized())
         self.overlap = overlap
+        # How a bucket's collective is issued (VJ_DP_COLL): "sync" (default) = async_op=False inside the communication stream's context --
+        # torch.distributed (>= 2.7) then launches the collective ON that stream, the one stream this engine has checked against the
+        # compute streams' hardware queues; "async" = async_op=True: ProcessGroupNCCL launches it on a pooled stream of ITS OWN, which
+        # nobody has checked -- when that stream shares a hardware queue with the main stream, its waits on the weight-gradient
+        # stream's events stall the main stream's kernels and the two-stream backward serialises (profiles/r05_queue_aliasing.md).
+        self.coll_mode = os.environ.get("VJ_DP_COLL", "sync")
+        if self.coll_mode not in ("sync", "async", "capi"):
+            raise ValueError(f"VJ_DP_COLL={self.coll_mode!r}: expected sync, async or capi")
+        self._capi = None      # (library, vj_comm_t handle) when VJ_DP_COLL=capi
+        self.extra_streams = []   # further streams the communication stream must not share a queue with (the deferred update's)
         self.buckets = {}      # (kind, layer) -> list of (lo, hi) ranges of arena.G that become final at that hook
         self.tail = []
         self._pending = []
@@ -67,6 +82,30 @@ class GradReducer:
             pos = max(pos, hi)
         if pos < total:
             self.tail.append((pos, total))
+        # VJ_DP_DIAG (one-rank diagnostics of the capi route, lab/trips/r05_trip19.sh): "extracomm" = create the C-ABI communicator but reduce
+        # through torch.distributed; "skipcall" = capi without the ncclAllReduce call itself (events and stream joins only)
+        self._diag = os.environ.get("VJ_DP_DIAG", "")
+        if (self.coll_mode == "capi" or self._diag == "extracomm") and arena.G.is_cuda:
+            self._init_capi(arena.G.device)
+            if self.coll_mode != "capi":
+                self._capi_unused, self._capi = self._capi, None
+
+    def _init_capi(self, device):
+        """RCCL communicator through the C ABI: rank 0 draws the unique id, the process group broadcasts it."""
+        import ctypes
+        from ..hip.lib import check, load_library
+        lib = load_library()
+        n = lib.vj_comm_unique_id_bytes()
+        idt = torch.zeros(n, dtype=torch.uint8, device=device)
+        if dist.get_rank() == 0:
+            buf = (ctypes.c_ubyte * n)()
+            check(lib.vj_comm_unique_id(buf), "vj_comm_unique_id")
+            idt.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        raw = bytes(idt.cpu().tolist())
+        handle = ctypes.c_void_p()
+        check(lib.vj_comm_init(ctypes.byref(handle), dist.get_rank(), dist.get_world_size(), raw), "vj_comm_init")
+        self._capi = (lib, handle)
 
     def begin(self, producer_stream=None):
         """producer_stream: the HIP stream on which the per-layer weight gradients are enqueued (the engine's side
@@ -83,7 +122,8 @@ class GradReducer:
             from .layers import independent_stream, side_stream
             dev = self.arena.G.device
             with torch.cuda.device(dev):
-                self.comm_stream = independent_stream(dev, [torch.cuda.current_stream(dev), side_stream(dev).stream])
+                others = [torch.cuda.current_stream(dev), side_stream(dev).stream] + [x for x in self.extra_streams if x is not None]
+                self.comm_stream = independent_stream(dev, others)
 
     def _reduce(self, lo, hi, producer=None):
         g = self.arena.G[lo:hi]
@@ -99,8 +139,17 @@ class GradReducer:
             self._ev_next = nxt + 1
             ev.record(producer if producer is not None else torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            if self._capi is not None:
+                from ..hip.lib import check
+                lib, handle = self._capi
+                if self._diag != "skipcall":
+                    check(lib.vj_comm_allreduce_bucket(handle, g.data_ptr(), g.numel(), self.comm_stream.cuda_stream), "vj_comm_allreduce_bucket")
+                return
             with torch.cuda.stream(self.comm_stream):
-                self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+                if self.coll_mode == "async":
+                    self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+                else:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)   # on comm_stream itself; finish() joins the stream
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
 

@@ -229,6 +229,7 @@ class Trainer:
         # operators right after train_step must then call sync_update() first (everything inside this package does).
         self.overlap_update = bool(overlap_update)
         self._upd_stream = self._make_update_stream() if self.overlap_update else None
+        self.reducer.extra_streams = [self._upd_stream]   # the communication stream is picked against this one too (first bucket)
         self._gates = None          # {'enc': [(first_block, event)], 'pred': [(0, event)], 'done': event} of the pending update
         self._plan = self._update_plan()
 
