@@ -606,6 +606,7 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
   for (int d = 0; d < DIST; d++)
     if (d < nt) issue(d, d * BUFB, std::false_type{});
   int cur_off = 0, nxt_off = DIST * BUFB;
+  const bool wave_live = qb * 128 + wu * (16 * QT) < S;   // wave-uniform
 
   // FIRST: tile 0 -- the base is unknown (seed 0), the exact-maximum path runs unconditionally and nothing is rescaled.
   auto iter = [&](const int t, auto fast_tag, auto first_tag) {
@@ -620,6 +621,10 @@ __global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_sm_kernel(const bf16_t* 
     else if (t + DIST < nt) issue(t + DIST, nxt_off, std::false_type{});
     cur_off = cur_off + BUFB == RINGB ? 0 : cur_off + BUFB;
     nxt_off = nxt_off + BUFB == RINGB ? 0 : nxt_off + BUFB;
+    // round 5: a wave all of whose queries lie beyond S (the last query block of a sequence that is not a multiple of 128: S = 264 ->
+    // three of the third block's four waves, a quarter of the segment's waves) takes part in the DMA and the barrier and leaves the pipes
+    // to the waves that have rows -- it stores nothing, so the results are untouched
+    if (!wave_live) return;
     // ---- S^T - m = K (cQ)^T - m : sacc[qt][kt] holds (s2 - mrun)[key = kt*16 + 4g + r][q = li] ----
     f32x4_t sacc[QT][4];
 #pragma unroll
@@ -841,6 +846,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
   float lse_r = 0.f, dl_r = 0.f;
   const f32x2_t sc2 = {sc, sc};
   const int nt = (S + 63) / 64;
+  const bool wave_live = kb * (64 * KT) + __builtin_amdgcn_readfirstlane(w) * (16 * KT) < S;   // wave-uniform
   const TileDma<HDP, 256> dma(tid, hd);
   auto load_stats = [&](int r0) {
     if (tid < 64) {
@@ -881,8 +887,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
     // a half, then its dV / dK MFMAs.  Per accumulator the operations and their order are those of the round-4 form (all four
     // 16-query blocks first, then both halves) -- bit-identical -- but only one half's P / dS is live at a time, which is what lets
     // KT = 4 (64 keys per wave: every Q / dO fragment, transposed read and statistics read serves FOUR key tiles) fit the registers.
+    // round 5: a wave all of whose keys lie beyond S skips the tile's arithmetic (it stores nothing), and a half all of whose QUERIES are
+    // padded rows is skipped by every wave (P = 0 there: it would add zeros to every accumulator)
+    if (!wave_live) continue;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
+      if (c == 1 && t * 64 + 32 >= S) break;
       float pv[KT][2][4], dsv[KT][2][4];
 #pragma unroll
       for (int q2 = 0; q2 < 2; q2++) {
@@ -1101,6 +1111,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   }
   const f32x2_t sc2 = {sc, sc};
   const int nt = (S + 63) / 64;
+  const bool wave_live = qb * (64 * QW) + __builtin_amdgcn_readfirstlane(w) * (16 * QW) < S;   // wave-uniform
   const TileDma<HDP, 256> dma(tid, hd);
   constexpr int NDMA2 = 2 * TileDma<HDP, 256>::NDMA;   // DMA instructions per wave per tile
   __builtin_amdgcn_s_waitcnt(0x0f70);   // compiler-visible vmcnt(0): the Q / dO / lse loads above are complete
@@ -1125,8 +1136,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     // Two halves of the 64-key tile (c = 0, 1: keys 32c .. 32c+31 = the contraction chunk of one dQ MFMA): S^T / dP^T / dS^T of a half
     // for all QW query tiles, then its dQ MFMAs.  Per accumulator the same operations in the same order as the round-4 form (all
     // four key blocks first, then both halves): bit-identical; only one half's scores are live, which is what lets QW = 4 fit.
+    // round 5: a wave all of whose queries lie beyond S skips the tile's arithmetic (it stores nothing), and a half all of whose KEYS are
+    // padded is skipped by every wave (its dS is set to zero below: it would add zeros to every dQ accumulator)
+    if (!wave_live) continue;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
+      if (c == 1 && k0 + 32 >= S) break;
       f32x4_t sacc[QW][2], dpacc[QW][2];
 #pragma unroll
       for (int qt = 0; qt < QW; qt++)
