@@ -16,3 +16,5 @@ db=$(find $O/prof_r05c -name "*results.db" | head -1); [ -n "$db" ] && python to
 find $O/prof_r05c -name "*.db" -delete
 grep -E "attn_|persist_pre_kernel<0" $O/prof_r05c.md | head -12
 (VJ_FORCE_DP=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline-pass > $O/r5t22_bench_dp1.json 2> $O/r5t22_bench_dp1.err; echo "rc=$?" >> $O/r5t22_bench_dp1.err); cut -c1-200 $O/r5t22_bench_dp1.json; tail -1 $O/r5t22_bench_dp1.err
+(timeout 400 python tools/abab.py --arms "base;r4like:gemm_epi_pre=0,upd_overlap=0" --rounds 8 --steps 6 --out $O/r5t22_abab.json > $O/r5t22_abab.md 2> $O/r5t22_abab.err; echo "rc=$?" >> $O/r5t22_abab.err)
+cat $O/r5t22_abab.md
