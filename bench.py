@@ -28,16 +28,15 @@ import time
 
 logging.basicConfig(stream=sys.stderr, level=logging.INFO)   # stdout carries the ONE JSON line and nothing else
 
-# The step runs on up to five HIP streams (dgrad chain, weight-gradient / target-forward stream, gradient-communication
-# stream, RCCL's internal stream under torch.distributed, input copy stream).  ROCm maps streams onto 4 hardware queues
-# by default; with a fifth stream two of them share a queue and serialise -- measured with the 1-rank RCCL reducer:
-# 101.2 ms/step (target forward no longer overlapped) vs 88.7 ms with 8 queues.  Must be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-import torch  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# Hardware queues: the PACKAGE decides (jepa_amd/__init__.py sets GPU_MAX_HW_QUEUES=6 unless the user exported a value, and says
+# why: with eight queues a second RCCL communicator slows every compute kernel, profiles/r05_dp1_coll_mode.md).  It must be
+# imported before torch initialises HIP; the value in force is reported in the JSON line (`config.hw_queues`).
+import jepa_amd  # noqa: E402,F401
+
+import torch  # noqa: E402
 
 VITL_MASKS = [  # configs/pretrain/vitl16.yaml:38-62
     dict(aspect_ratio=(0.75, 1.5), num_blocks=8, spatial_scale=(0.15, 0.15), temporal_scale=(1.0, 1.0),
@@ -234,6 +233,21 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
+def per_rank(x, world, device):
+    """[x of rank 0, ..., x of rank world-1] on every rank (the scaling line reports the spread: with per-rank mask draws the slowest
+    rank sets the pace, and a max alone cannot tell that skew from communication)."""
+    if world <= 1 or not torch.distributed.is_initialized():
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    torch.distributed.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def spread(vals, scale=1.0, nd=3):
+    return {"min": round(min(vals) * scale, nd), "mean": round(sum(vals) / len(vals) * scale, nd), "max": round(max(vals) * scale, nd)}
+
+
 def stub_main(args):
     """Launcher rehearsal without a GPU (tests/test_bench_launch.py): the same argument handling, self-launch, rendezvous,
     fences, max-over-ranks timing and one-line report as the real run, over a gloo group, with the step replaced by a
@@ -249,10 +263,15 @@ def stub_main(args):
     B = args.batch or WORKLOADS[args.workload]["batch"]
     buf = torch.ones(64)
 
+    waited = [0.0]
+
     def run(i):
         time.sleep(args.stub_step_ms * 1e-3 * (1.0 + 0.5 * rank))   # rank r is slower: the report must carry the MAX
         if world > 1:
-            torch.distributed.all_reduce(buf)
+            t_c = time.perf_counter()
+            torch.distributed.all_reduce(buf)     # a fast rank waits here for the slow one: "exposed communication" of the stub
+            if i >= args.warmup:
+                waited[0] += time.perf_counter() - t_c
         return i
 
     def sync():
@@ -260,9 +279,14 @@ def stub_main(args):
             torch.distributed.barrier()
 
     elapsed, _, _, _ = timed_loop(run, sync, args.warmup, args.steps)
+    ranks_ms = [1e3 * e / args.steps for e in per_rank(elapsed, world, torch.device("cpu"))]
+    exs = per_rank(1e3 * waited[0] / args.steps, world, torch.device("cpu"))
     elapsed = max_over_ranks(elapsed, world, torch.device("cpu"))
     if rank == 0:
         print(json.dumps({
+            "dp": {"ranks": world, "backend": "gloo (stub)", "route": "blocking", "collectives": "stub",
+                   "collective_stream_check": None, "rank_ms_per_step": spread(ranks_ms), "rank_exposed_comm_ms": spread(exs),
+                   "rank_compute_ms_per_step": spread([a - b for a, b in zip(ranks_ms, exs)])},
             "metric": "V-JEPA pretrain clips/sec (fwd+bwd+EMA)", "value": round(B * world * args.steps / elapsed, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -347,6 +371,7 @@ def main():
         torch.cuda.synchronize()
 
     elapsed, host_enqueue, t_first, last = timed_loop(run, sync, args.warmup, args.steps)
+    ranks_ms = [1e3 * e / args.steps for e in per_rank(elapsed, world, device)]   # every rank's own clock around the same K steps
     log(f"host enqueue time {1e3 * host_enqueue / args.steps:.1f} ms/step incl. queue back-pressure, "
         f"{1e3 * t_first:.1f} ms for the first step (GPU step {1e3 * elapsed / args.steps:.1f} ms)")
     dp_info = None
@@ -359,7 +384,16 @@ def main():
         from jepa_amd.engine import layers as _layers
         log(f"collectives issued {trainer.reducer.coll_mode!r}; stream picks (candidate index, concurrent with each stream it must not share a "
             f"hardware queue with): {_layers._INDEP_LOG}")
-        dp_info = {"ranks": world, "backend": "rccl via the C ABI (vj_comm_*)" if trainer.reducer.coll_mode == "capi" else "rccl via torch.distributed", "collectives": trainer.reducer.coll_mode,
+        route = trainer.reducer.route     # the route the buckets actually took (a failed stream check switches sync -> capi)
+        exs = per_rank(trainer.reducer.exposed_ms() or 0.0, world, device)
+        dp_info = {"ranks": world, "backend": "rccl via the C ABI (vj_comm_*)" if route == "capi" else "rccl via torch.distributed",
+                   "collectives": trainer.reducer.coll_mode, "route": route,
+                   "collective_stream_check": trainer.reducer.coll_check,
+                   "rank_ms_per_step": spread(ranks_ms), "rank_exposed_comm_ms": spread(exs),
+                   # a rank's own work = its step time minus what its compute stream waited for the collectives (a fast rank waits there
+                   # for the slowest one's mask draw): a wide spread HERE is skew, a large exposed time on EVERY rank is communication
+                   "rank_compute_ms_per_step": spread([a - b for a, b in zip(ranks_ms, exs)]),
+                   "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "layer_buckets": len(trainer.reducer.buckets), "tail_ranges": len(trainer.reducer.tail),
                    "grad_bytes_per_step": int(trainer.arena.total * 4),
                    "exposed_comm_ms_per_step": None if ex is None else round(ex, 3),
@@ -520,7 +554,8 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "global_batch": B * world, "per_gpu_batch": B,
-                       "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+                       "parallelism": f"dp{world}", "final_loss": round(loss, 6),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if dp_info is not None:

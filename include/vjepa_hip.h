@@ -38,7 +38,8 @@ int vj_gather_rows(const void* src, void* dst, const int64_t* idx, int64_t B, in
  * dst[B,N,row] is zero-filled, then dst[b, idx[b,k], :] = src[b,k,:]. */
 int vj_scatter_rows(const void* src, void* dst, const int64_t* idx, int64_t B, int64_t N, int64_t K,
                     int64_t row_bytes, vj_stream_t stream);
-/* bf16 row-slice copy: dst[b, dst_off+j, :] = src[b, src_off+j, :], j < n  (x[:, N_ctxt:], predictor.py:236) */
+/* bf16 row-slice copy: dst[b, dst_off+j, :] = src[b, src_off+j, :], j < n  (x[:, N_ctxt:], predictor.py:236);
+ * src == NULL zero-fills those destination rows instead (autograd's zero gradient of the rows x[:, :N_ctxt] that the slice drops) */
 int vj_copy_rows(const void* src, void* dst, int64_t B, int64_t src_rows, int64_t src_off, int64_t dst_rows,
                  int64_t dst_off, int64_t n, int64_t D, vj_stream_t stream);
 
@@ -397,6 +398,10 @@ int vj_probe_lds_bw(long long* out, int mode, int iters, int n_wgs, vj_stream_t 
 /* one wave idling for `ticks` periods of the 100 MHz timer: two of them on two streams take one spin time iff the streams are
  * mapped to different hardware queues (used once per process to pick independent side / update / communication streams) */
 int vj_probe_spin(int64_t ticks, vj_stream_t stream);
+/* the same kernel leaving {start, end} of its spin on the chip-wide 100 MHz timer in stamps[0..1] (device memory): two of them on two
+ * streams overlap ON THE DEVICE'S CLOCK iff the streams sit on different hardware queues; no host timing involved (what
+ * engine/layers.py streams_concurrent uses since round 6).  No reference counterpart. */
+int vj_probe_spin_stamped(int64_t ticks, int64_t* stamps, vj_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -110,7 +110,10 @@ def init_opt(encoder, predictor, iterations_per_epoch, start_lr, ref_lr, warmup,
         target_encoder = copy.deepcopy(encoder)
         for p in target_encoder.parameters():
             p.requires_grad = False
-        logger.info('init_opt: no target_encoder= given; the EMA target is optimizer.target_encoder (deep copy of encoder)')
+        import warnings
+        warnings.warn('jepa_amd init_opt: no target_encoder= given -- the EMA target is optimizer.target_encoder (a deep copy of the '
+                      'encoder, updated by the fused optimizer kernel); a target copy kept and EMA-updated by the caller would be a '
+                      'SECOND target that this optimizer never writes', stacklevel=2)
     optimizer = Trainer(encoder, predictor, target_encoder, loss_exp=loss_exp, reg_coeff=reg_coeff, betas=betas,
                         eps=eps, clip_grad=clip_grad, world_size=world_size, device=device, micro_batch=micro_batch,
                         overlap_update=overlap_update)

@@ -99,18 +99,31 @@ extern "C" int vj_probe_lds_bw(long long* out, int mode, int iters, int n_wgs, h
 // to the SAME hardware queue (ROCclr hands its GPU_MAX_HW_QUEUES queues to streams round-robin).  The engine uses it once per
 // process to choose side / update / communication streams that are independent of each other (engine/layers.py independent_stream):
 // a side stream that shares the main stream's queue turns the two-stream step into a serial one (+19 % measured, round 5).
-__global__ void probe_spin_kernel(long long ticks, long long* sink) {
+__global__ void probe_spin_kernel(long long ticks, long long* stamps) {
   const long long t0 = wall_clock64();
   long long t = t0;
   while (t - t0 < ticks) {
     __builtin_amdgcn_s_sleep(32);
     t = wall_clock64();
   }
-  if (sink != nullptr && threadIdx.x == 0) *sink = t - t0;
+  if (stamps != nullptr && threadIdx.x == 0) {   // {start, end} on the chip-wide 100 MHz timer
+    stamps[0] = t0;
+    stamps[1] = t;
+  }
 }
 extern "C" int vj_probe_spin(int64_t ticks, hipStream_t stream) {
   VJ_CHECK_ARG(ticks >= 0 && ticks <= 100000000, "vj_probe_spin: ticks (100 MHz) outside [0, 1e8]");
   hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, stream, (long long)ticks, (long long*)nullptr);
   VJ_LAUNCH_CHECK("vj_probe_spin");
+  return 0;
+}
+// The same kernel leaving its start and end stamps (the chip-wide constant 100 MHz timer, identical on every CU) in stamps[0..1]
+// (device memory): two of them on two streams OVERLAP on the device's own clock iff the streams sit on different hardware queues --
+// the host's wall clock, which 8 ranks and their data-loader workers perturb, is not involved (round-5 advisor finding).
+extern "C" int vj_probe_spin_stamped(int64_t ticks, int64_t* stamps, hipStream_t stream) {
+  VJ_CHECK_ARG(ticks >= 0 && ticks <= 100000000, "vj_probe_spin_stamped: ticks (100 MHz) outside [0, 1e8]");
+  VJ_CHECK_ARG(stamps != nullptr, "vj_probe_spin_stamped: null stamps");
+  hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, stream, (long long)ticks, (long long*)stamps);
+  VJ_LAUNCH_CHECK("vj_probe_spin_stamped");
   return 0;
 }

@@ -510,8 +510,9 @@ extern "C" int vj_colsum_bf16(const void* in, int64_t M, int64_t N, int64_t ld, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// copy_rows_strided: dst[b, j, :] = src[b, src_off + j, :] for j < rows_per  (bf16 rows; used to split the
-// predictor stream into its context rows (grad of predictor_embed) and to slice target rows).
+// copy_rows_strided: dst[b, dst_off + j, :] = src[b, src_off + j, :] for j < n  (bf16 rows; used to split the
+// predictor stream into its context rows (grad of predictor_embed) and to slice target rows).  src == nullptr: the
+// destination rows are ZEROED (the context rows of the predictor trunk's output gradient: no ATen fill on the step).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
                                                         int64_t B, int64_t src_rows, int64_t src_off,
@@ -521,16 +522,20 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* __restrict
   const int64_t nw = (int64_t)gridDim.x * 4;
   for (int64_t r = wave; r < B * n; r += nw) {
     const int64_t b = r / n, j = r - b * n;
-    const u32x4_t* sp = (const u32x4_t*)(src + (b * src_rows + src_off + j) * D);
     u32x4_t* dp = (u32x4_t*)(dst + (b * dst_rows + dst_off + j) * D);
-    for (int c = lane; c < D / 8; c += 64) dp[c] = sp[c];
+    if (src != nullptr) {   // (kernel argument: uniform)
+      const u32x4_t* sp = (const u32x4_t*)(src + (b * src_rows + src_off + j) * D);
+      for (int c = lane; c < D / 8; c += 64) dp[c] = sp[c];
+    } else {
+      for (int c = lane; c < D / 8; c += 64) dp[c] = (u32x4_t){0u, 0u, 0u, 0u};
+    }
   }
 }
 
 extern "C" int vj_copy_rows(const void* src, void* dst, int64_t B, int64_t src_rows, int64_t src_off,
                             int64_t dst_rows, int64_t dst_off, int64_t n, int64_t D, hipStream_t stream) {
   VJ_CHECK_ARG(D % 8 == 0, "vj_copy_rows: D must be a multiple of 8");
-  VJ_CHECK_ARG(src_off + n <= src_rows && dst_off + n <= dst_rows, "vj_copy_rows: slice out of range");
+  VJ_CHECK_ARG((src == nullptr || src_off + n <= src_rows) && dst_off + n <= dst_rows, "vj_copy_rows: slice out of range");
   if (B * n == 0) return 0;
   hipLaunchKernelGGL(copy_rows_kernel, dim3(rows_grid(B * n)), dim3(256), 0, stream, (const bf16_t*)src,
                      (bf16_t*)dst, B, src_rows, src_off, dst_rows, dst_off, n, (int)D);

@@ -85,6 +85,11 @@ class GradReducer:
         # VJ_DP_DIAG (one-rank diagnostics of the capi route, lab/trips/r05_trip19.sh): "extracomm" = create the C-ABI communicator but reduce
         # through torch.distributed; "skipcall" = capi without the ncclAllReduce call itself (events and stream joins only)
         self._diag = os.environ.get("VJ_DP_DIAG", "")
+        self.coll_check = None   # outcome of verify_collective_stream() (bench.py prints it in the `dp` object)
+        if self.coll_mode == "capi" and not (arena.G.is_cuda and overlap):
+            # (round-5 advisor finding: this used to fall back to torch.distributed silently while bench.py reported the C ABI)
+            raise ValueError("VJ_DP_COLL=capi needs the gradient arena on a GPU and overlap_comm=True: the C-ABI collectives are "
+                             "issued on the engine's communication stream")
         if (self.coll_mode == "capi" or self._diag == "extracomm") and arena.G.is_cuda:
             self._init_capi(arena.G.device)
             if self.coll_mode != "capi":
@@ -106,6 +111,87 @@ class GradReducer:
         handle = ctypes.c_void_p()
         check(lib.vj_comm_init(ctypes.byref(handle), dist.get_rank(), dist.get_world_size(), raw), "vj_comm_init")
         self._capi = (lib, handle)
+        import weakref
+        weakref.finalize(self, lib.vj_comm_destroy, handle)   # the communicator lives as long as the reducer (also the diagnostic one)
+
+    @property
+    def route(self):
+        """The route the buckets actually take: 'capi' (vj_comm_* on the engine's communication stream), 'sync' / 'async'
+        (torch.distributed on that stream / on ProcessGroupNCCL's own), or 'blocking' (no overlap: CPU tensors, overlap_comm=False)."""
+        if not (self.arena.G.is_cuda and self.overlap):
+            return "blocking"
+        return "capi" if self._capi is not None else self.coll_mode
+
+    def prepare(self, producer_stream=None):
+        """Pick the communication stream and check where the process group's collectives really land -- at construction time of the
+        Trainer (every rank calls it: the check issues two tiny collectives), not inside the first backward."""
+        if not (self.enabled and self.arena.G.is_cuda and self.overlap):
+            return
+        self._pick_comm_stream()
+        import os
+        if self.coll_mode == "sync" and self._capi is None and os.environ.get("VJ_DP_VERIFY", "1") != "0":
+            self.coll_check = self.verify_collective_stream()
+            if self.coll_check["verdict"] == "other-stream":
+                import warnings
+                warnings.warn("jepa_amd: torch.distributed launched a blocking collective on a stream of its own instead of the current "
+                              f"(communication) stream ({self.coll_check}); switching the gradient buckets to the C-ABI route (vj_comm_*), "
+                              "which takes the stream as an argument")
+                self._init_capi(self.arena.G.device)
+                self.coll_check["fallback"] = "capi"
+
+    def _pick_comm_stream(self):
+        if self.comm_stream is not None:
+            return
+        # a communication stream that shares a hardware queue with neither compute stream: on a shared queue the collectives
+        # and the backward serialise (engine/layers.py independent_stream)
+        from .layers import independent_stream, side_stream
+        dev = self.arena.G.device
+        with torch.cuda.device(dev):
+            others = [torch.cuda.current_stream(dev), side_stream(dev).stream] + [x for x in self.extra_streams if x is not None]
+            self.comm_stream = independent_stream(dev, others)
+
+    def verify_collective_stream(self):
+        """`sync` mode rests on a torch behaviour: ProcessGroupNCCL launches an async_op=False collective on the CURRENT stream
+        (torch >= 2.7).  Nothing in torch's API says which stream a collective used, so one small all-reduce + all-gather are traced
+        with torch.profiler (roctracer) next to a marker kernel issued on the communication stream, and the stream ids of the device
+        activities are compared.  -> {'verdict': 'comm-stream' | 'other-stream' | 'unobserved' | 'unavailable', ...}.
+        'unobserved': the collectives produced no device activity (a one-rank in-place all-reduce is a no-op) -- nothing to disprove."""
+        from ..hip.lib import check, load_library
+        out = {"verdict": "unavailable", "marker_stream": None, "collective_streams": [], "activities": []}
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            lib = load_library()
+            dev = self.arena.G.device
+            t = torch.ones(4096, dtype=torch.float32, device=dev)
+            g = torch.empty(4096 * max(1, dist.get_world_size()), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize(dev)
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                check(lib.vj_probe_spin(1000, self.comm_stream.cuda_stream), "vj_probe_spin")   # 10 us marker on the comm stream
+                with torch.cuda.stream(self.comm_stream):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    dist.all_gather_into_tensor(g, t)
+                torch.cuda.synchronize(dev)
+            marker, colls = None, []
+            for e in prof.events():
+                if str(e.device_type).endswith("CPU"):
+                    continue
+                nm = e.name.lower()
+                if "probe_spin" in nm:
+                    marker = e.device_resource_id
+                elif any(k in nm for k in ("nccl", "rccl", "allreduce", "allgather", "all_reduce", "all_gather", "memcpy", "copy")):
+                    colls.append((e.name[:48], e.device_resource_id))
+            out["marker_stream"] = marker
+            out["activities"] = colls[:6]
+            out["collective_streams"] = sorted({sid for _, sid in colls})
+            if marker is None:
+                out["verdict"] = "unavailable"
+            elif not colls:
+                out["verdict"] = "unobserved"
+            else:
+                out["verdict"] = "comm-stream" if all(sid == marker for _, sid in colls) else "other-stream"
+        except Exception as ex:   # no tracer in this build / a tracer already attached (rocprofv3): keep the route, say so
+            out["error"] = f"{type(ex).__name__}: {ex}"[:200]
+        return out
 
     def begin(self, producer_stream=None):
         """producer_stream: the HIP stream on which the per-layer weight gradients are enqueued (the engine's side
@@ -117,13 +203,7 @@ class GradReducer:
         self._ev_next = 0           # ordering events are pooled: one per bucket position, re-recorded every step
         self._producer = producer_stream
         if self.arena.G.is_cuda and self.overlap and self.comm_stream is None:
-            # a communication stream that shares a hardware queue with neither compute stream: on a shared queue the collectives
-            # and the backward serialise (engine/layers.py independent_stream)
-            from .layers import independent_stream, side_stream
-            dev = self.arena.G.device
-            with torch.cuda.device(dev):
-                others = [torch.cuda.current_stream(dev), side_stream(dev).stream] + [x for x in self.extra_streams if x is not None]
-                self.comm_stream = independent_stream(dev, others)
+            self._pick_comm_stream()   # (normally done by prepare() when the Trainer is built)
 
     def _reduce(self, lo, hi, producer=None):
         g = self.arena.G[lo:hi]

@@ -72,23 +72,26 @@ _INDEP_LOG = []   # (candidate index, [concurrent with others[i]]) of every inde
 
 
 def streams_concurrent(a, b, spin_us=300.0):
-    """True when a kernel on stream `a` and one on stream `b` run at the same time (different hardware queues): two idle
-    one-wave kernels of `spin_us` each (vj_probe_spin), wall-clock around both.  Synchronises the device."""
-    import time
+    """True when a kernel on stream `a` and one on stream `b` run at the same time (different hardware queues): two idle one-wave
+    kernels of `spin_us` each (vj_probe_spin_stamped) leave their start / end stamps of the chip-wide 100 MHz timer in device memory;
+    the streams are concurrent when the two intervals overlap by more than half a spin.  Judged on the DEVICE's clock (round 6; it was
+    host wall-clock time around both, which eight ranks and their loader workers can stretch past any threshold).  Synchronises the
+    two streams."""
     from ..hip.lib import check, load_library
     lib = load_library()
     ticks = int(spin_us * 100)
-    best = None
+    dev = a.device if hasattr(a, "device") else torch.device("cuda", torch.cuda.current_device())
+    stamps = torch.zeros(4, dtype=torch.int64, device=dev)
+    torch.cuda.current_stream(dev).synchronize()      # the zero fill is complete before either probe writes
+    best = 0
     for _ in range(2):                       # the first pass also pays one-time costs (code load, queue creation)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        check(lib.vj_probe_spin(ticks, a.cuda_stream), "vj_probe_spin")
-        check(lib.vj_probe_spin(ticks, b.cuda_stream), "vj_probe_spin")
+        check(lib.vj_probe_spin_stamped(ticks, stamps.data_ptr(), a.cuda_stream), "vj_probe_spin_stamped")
+        check(lib.vj_probe_spin_stamped(ticks, stamps.data_ptr() + 16, b.cuda_stream), "vj_probe_spin_stamped")
         a.synchronize()
         b.synchronize()
-        dt = (time.perf_counter() - t0) * 1e6
-        best = dt if best is None else min(best, dt)
-    return best < 1.6 * spin_us
+        a0, a1, b0, b1 = stamps.tolist()
+        best = max(best, min(a1, b1) - max(a0, b0))
+    return best > ticks // 2
 
 
 def independent_stream(device, others, make=None, tries=16):
@@ -442,8 +445,9 @@ def predictor_backward(dzhat, saved, pw: PredictorW, enc_segs, alpha: float, on_
     last_gb = pw.blocks[-1].fc2.gb if _tn_ok(8, 8) else None
     dt = ops.layernorm_bwd(dtn, t, pw.norm.g, mean, rstd, pw.norm.gg, pw.norm.gb, alpha=alpha, accumulate=acc, dxsum=last_gb)
     total = segs[-1].row0 + segs[-1].rows
-    dx = torch.zeros((total, Dp), dtype=torch.bfloat16, device=dzhat.device)  # context rows start at zero grad
+    dx = torch.empty((total, Dp), dtype=torch.bfloat16, device=dzhat.device)
     for sg, psg, tsg in zip(enc_segs, segs, tsegs):
+        ops.copy_rows(None, _rows(dx, psg), psg.B, 0, 0, psg.S, 0, sg.S, Dp)   # context rows start at zero grad (no ATen fill on the step)
         ops.copy_rows(_rows(dt, tsg), _rows(dx, psg), psg.B, tsg.S, 0, psg.S, sg.S, tsg.S, Dp)
     if on_layer_done is not None:
         on_layer_done("pred", len(pw.blocks))

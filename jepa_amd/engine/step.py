@@ -229,7 +229,8 @@ class Trainer:
         # operators right after train_step must then call sync_update() first (everything inside this package does).
         self.overlap_update = bool(overlap_update)
         self._upd_stream = self._make_update_stream() if self.overlap_update else None
-        self.reducer.extra_streams = [self._upd_stream]   # the communication stream is picked against this one too (first bucket)
+        self.reducer.extra_streams = [self._upd_stream]   # the communication stream is picked against this one too
+        self.reducer.prepare()   # communication stream + where torch.distributed's collectives land: now, not inside the first backward
         self._gates = None          # {'enc': [(first_block, event)], 'pred': [(0, event)], 'done': event} of the pending update
         self._plan = self._update_plan()
 
@@ -370,6 +371,9 @@ class Trainer:
         from .layers import independent_stream
         with torch.cuda.device(self.device):
             others = [torch.cuda.current_stream(self.device), side_stream(self.device).stream]
+            comm = getattr(getattr(self, "reducer", None), "comm_stream", None)
+            if comm is not None:   # (created late, after the reducer picked its communication stream)
+                others.append(comm)
             make = (lambda: low_priority_stream(self.device)) if _UPD_LOW_PRIO else None
             return independent_stream(self.device, others, make=make)
 
@@ -380,8 +384,12 @@ class Trainer:
         """Make the current stream wait for a pending update (overlap_update): call before reading parameters, moments or
         the EMA target with plain torch operators right after train_step.  No-op otherwise."""
         if self._gates is not None:
-            torch.cuda.current_stream().wait_event(self._gates["done"])
-            self._gates = None
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._gates["done"])
+            # only the stream the step runs on may retire the gates: called under a user's stream (logging, checkpointing), the next
+            # train_step on the training stream still has to wait for the update (round-5 advisor finding)
+            if self._gates.get("stream") is None or cur == self._gates["stream"]:
+                self._gates = None
 
     def _update_plan(self):
         """[(which, first_block, [(group, lo, hi)])]: the arena ranges of the fused update in the order the forward reads
@@ -476,6 +484,7 @@ class Trainer:
                 done = torch.cuda.Event()
                 done.record(upd)
             gates["done"] = done
+            gates["stream"] = main
             self._gates = gates
             _weights.PENDING_UPDATE[self.device.index] = done
         else:

@@ -129,6 +129,7 @@ SIGNATURES = {
     "vj_probe_lds_bw": (I32, [P, I32, I32, I32, P]),
     "vj_ws_guard_check": (I32, [I64P, I64P]),
     "vj_probe_spin": (I32, [I64, P]),
+    "vj_probe_spin_stamped": (I32, [I64, P, P]),
 }
 
 

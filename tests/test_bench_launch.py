@@ -37,6 +37,19 @@ def test_self_launch_two_ranks():
     # rank 1 sleeps 1.5 x 20 ms per step: the reported time is the slowest rank's, not rank 0's
     assert line["ms_per_step"] >= 29.0, line
     assert abs(line["value"] - line["config"]["global_batch"] / (line["ms_per_step"] * 1e-3)) < 0.01 * line["value"]
+    # the data-parallel object: per-rank step-time spread (tells mask-draw skew from communication), the route the buckets took and
+    # the outcome of the collective-stream check (round 6)
+    dp = line["dp"]
+    for key in ("ranks", "route", "collectives", "collective_stream_check", "rank_ms_per_step", "rank_exposed_comm_ms",
+                "rank_compute_ms_per_step"):
+        assert key in dp, dp
+    sp = dp["rank_ms_per_step"]
+    assert sp["min"] <= sp["mean"] <= sp["max"] and abs(sp["max"] - line["ms_per_step"]) < 0.5
+    # the all-reduce equalises the ranks' step times; their OWN work (step time minus the wait in the collective) shows that rank 1
+    # sleeps 1.5 x as long as rank 0, and the fast rank's wait is about the difference
+    cp, ex = dp["rank_compute_ms_per_step"], dp["rank_exposed_comm_ms"]
+    assert cp["max"] >= 1.3 * cp["min"], dp
+    assert ex["max"] >= 5.0 and ex["min"] <= 0.5 * ex["max"], dp
 
 
 def test_external_launcher_still_works():
