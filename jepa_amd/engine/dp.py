@@ -129,15 +129,21 @@ class GradReducer:
             return
         self._pick_comm_stream()
         import os
-        if self.coll_mode == "sync" and self._capi is None and os.environ.get("VJ_DP_VERIFY", "1") != "0":
+        # (only RCCL groups: a gloo group -- the two-ranks-on-one-GPU parity test -- reduces on the host, there is no stream to check)
+        if (self.coll_mode == "sync" and self._capi is None and os.environ.get("VJ_DP_VERIFY", "1") != "0"
+                and dist.get_backend() == "nccl"):
             self.coll_check = self.verify_collective_stream()
             if self.coll_check["verdict"] == "other-stream":
                 import warnings
                 warnings.warn("jepa_amd: torch.distributed launched a blocking collective on a stream of its own instead of the current "
                               f"(communication) stream ({self.coll_check}); switching the gradient buckets to the C-ABI route (vj_comm_*), "
                               "which takes the stream as an argument")
-                self._init_capi(self.arena.G.device)
-                self.coll_check["fallback"] = "capi"
+                try:
+                    self._init_capi(self.arena.G.device)
+                    self.coll_check["fallback"] = "capi"
+                except Exception as ex:   # keep the working (if slower) route rather than lose the run
+                    self._capi = None
+                    self.coll_check["fallback"] = f"capi unavailable ({type(ex).__name__}): staying on torch.distributed"
 
     def _pick_comm_stream(self):
         if self.comm_stream is not None:

@@ -369,7 +369,7 @@ def attn_bwd(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None):
     lib = load_library()
     _req(dout, BF16, "dout")
     dqkv = torch.empty_like(qkv) if out is None else out
-    nws = lib.vj_attn_bwd_ws_bytes(B, S, H)
+    nws = lib.vj_attn_bwd_segs_ws_bytes(_seg_array([(0, B, S)]), 1, H, hd)
     ws = Scratch.get(nws, qkv.device, "attn", stream=stream)
     _ev = _timed("attn_bwd", 8.0 * B * H * S * S * hd)
     check(lib.vj_attn_bwd(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), B, S, H, hd, scale, _ptr(ws), nws,
@@ -408,7 +408,9 @@ def attn_bwd_segs(qkv, o, dout, lse, segs, H, hd, scale, colsum=False, stream=No
     _req(dout, BF16, "dout")
     M = qkv.shape[0]
     dqkv = torch.empty_like(qkv)
-    ws = Scratch.get(4 * H * M, qkv.device, "attn", stream=stream)
+    seg_arr = _seg_array(segs)
+    nws = lib.vj_attn_bwd_segs_ws_bytes(seg_arr, len(segs), H, hd)
+    ws = Scratch.get(nws, qkv.device, "attn", stream=stream)
     colq = colkv = None
     if colsum:
         rq_t = rkv_t = 0
@@ -418,8 +420,8 @@ def attn_bwd_segs(qkv, o, dout, lse, segs, H, hd, scale, colsum=False, stream=No
             rq_t, rkv_t = rq_t + (rq.value if B * S else 0), rkv_t + (rkv.value if B * S else 0)
         colq = torch.empty((rq_t, H * hd), dtype=F32, device=qkv.device)
         colkv = torch.empty((rkv_t, 2 * H * hd), dtype=F32, device=qkv.device)
-    check(lib.vj_attn_bwd_segs(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), _seg_array(segs), len(segs), H, hd, scale,
-                               _ptr(ws), 4 * H * M, _ptr(colq), _ptr(colkv), _stream(stream)), "vj_attn_bwd_segs")
+    check(lib.vj_attn_bwd_segs(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), seg_arr, len(segs), H, hd, scale,
+                               _ptr(ws), nws, _ptr(colq), _ptr(colkv), _stream(stream)), "vj_attn_bwd_segs")
     return (dqkv, colq, colkv) if colsum else dqkv
 
 
@@ -434,7 +436,7 @@ def attn_bwd_colsum(qkv, o, dout, lse, B, S, H, hd, scale, out=None, stream=None
     check(lib.vj_attn_bwd_colsum_rows(B, S, hd, ctypes.byref(rq), ctypes.byref(rkv)), "vj_attn_bwd_colsum_rows")
     colq = torch.empty((rq.value, H * hd), dtype=F32, device=qkv.device)
     colkv = torch.empty((rkv.value, 2 * H * hd), dtype=F32, device=qkv.device)
-    nws = lib.vj_attn_bwd_ws_bytes(B, S, H)
+    nws = lib.vj_attn_bwd_segs_ws_bytes(_seg_array([(0, B, S)]), 1, H, hd)
     ws = Scratch.get(nws, qkv.device, "attn", stream=stream)
     check(lib.vj_attn_bwd_colsum(_ptr(qkv), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dqkv), B, S, H, hd, scale, _ptr(ws), nws,
                                  _ptr(colq), _ptr(colkv), _stream(stream)), "vj_attn_bwd_colsum")
