@@ -169,8 +169,6 @@ typedef struct vj_seg {
 } vj_seg_t;
 int vj_attn_fwd_segs(const void* qkv, void* o, float* lse2, const vj_seg_t* segs, int64_t n_segs, int64_t H, int64_t hd,
                      float scale, vj_stream_t stream);
-/* tuning switch (benchmarks only): 16-row query tiles per wave in the forward kernel, 2 (default) or 1 */
-int vj_attn_set_variant(int fwd_qt);
 int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H);   /* the two-kernel form's delta [B,H,S] only: prefer the next one */
 /* workspace bytes of vj_attn_bwd / vj_attn_bwd_segs / vj_attn_bwd_colsum for a segment list: delta = rowsum(dO . O) of the softmax
  * backward (autograd of modules.py:66-69), 4*H bytes per token row up to the last row of the list */

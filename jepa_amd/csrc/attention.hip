@@ -21,239 +21,8 @@
 #include "attn_common.hpp"
 
 // =============================================================================================================
-// forward:  O = softmax(Q K^T * scale) V,  128 queries per workgroup (32 per wave), 64-key tiles
-// =============================================================================================================
-template <int HDP, int QT, int NBUF>
-__global__ __launch_bounds__(8 * 64 / QT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                       float* __restrict__ lse2, int B, int S, int H, int hd,
-                                                       float sc, int nqb) {
-  constexpr int NT = 8 * 64 / QT;   // 128 queries per workgroup, 16*QT per wave
-  using RT = RowTile<HDP, NT>;
-  // {K,V} x NBUF buffers, filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write): the DMA
-  // destination is lane-linear, so the XOR swizzle of the row-major image is applied on the per-lane SOURCE chunk.
-  constexpr int DIST = NBUF - 1;   // prefetch distance in tiles
-  static_assert(RT::CAN_FULL || NT == 512, "tile items must be a multiple of the workgroup size");
-  constexpr int NDMA = RT::CAN_FULL ? RT::NIT : 1;            // DMA instructions per wave per K (or V) tile
-  __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * RT::BYTES];
-  const TrFrag<HDP> trf(threadIdx.x & 63);
-  constexpr int KS = HDP / 32, DT = HeadTiles<HDP>::DT;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int li = lane & 15, g = lane >> 4;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = logical % nqb, bh = logical / nqb;
-  const int h = bh % H, b = bh / H;
-  const int64_t rs = (int64_t)3 * H * hd;
-  const bf16_t* qbase = qkv + (int64_t)b * S * rs + (int64_t)h * hd;
-  const bf16_t* kbase = qbase + (int64_t)H * hd;
-  const bf16_t* vbase = qbase + (int64_t)2 * H * hd;
-  const int q0 = qb * 128 + w * (16 * QT);
-
-  bf16x8_t qf[QT][KS];
-#pragma unroll
-  for (int qt = 0; qt < QT; qt++)
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      const int q = q0 + qt * 16 + li, d0 = ks * 32 + 8 * g;
-      qf[qt][ks] = load_frag_global(qbase + (int64_t)q * rs + d0, q < S && d0 < hd);
-    }
-
-  f32x4_t oacc[QT][DT];
-#pragma unroll
-  for (int qt = 0; qt < QT; qt++)
-#pragma unroll
-    for (int dt = 0; dt < DT; dt++) oacc[qt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float mrun[QT], lrun[QT];
-#pragma unroll
-  for (int qt = 0; qt < QT; qt++) {
-    mrun[qt] = -INFINITY;
-    lrun[qt] = 0.f;
-  }
-
-  const int nt = (S + 63) / 64;
-  // per-lane source of DMA item it: row (item / CHP) of the tile, chunk (item % CHP) ^ swizzle(row); chunks beyond
-  // the real head dimension re-read chunk 0 (they only meet zero Q chunks / produce discarded O columns) and rows
-  // beyond S re-read row S-1 (their scores are masked to -inf, P = 0): the DMA never needs a zero fill.
-  int dma_row[NDMA];
-  unsigned dma_voff[NDMA], dma_col2[NDMA];   // byte offsets inside a tile: (row * rs + col) * 2 and col * 2
-  const bool dma_on = RT::CAN_FULL || tid < 64 * RT::CHP;
-#pragma unroll
-  for (int it = 0; it < NDMA; it++) {
-    const int item = RT::CAN_FULL ? tid + it * NT : (tid < 64 * RT::CHP ? tid : 0);
-    const int row = item / RT::CHP, c = (item % RT::CHP) ^ rm_swz<HDP>(row);
-    const int col = c * 8 < hd ? c * 8 : 0;
-    dma_row[it] = row;
-    dma_col2[it] = (unsigned)col * 2u;
-    dma_voff[it] = ((unsigned)row * (unsigned)rs + (unsigned)col) * 2u;
-  }
-  const int64_t v_off = (int64_t)H * hd;
-  const int wu = __builtin_amdgcn_readfirstlane(w);
-  const unsigned rs2 = (unsigned)rs * 2u;
-  // wave-uniform tile base (SGPRs) + 32-bit per-lane offset: the steady state spends no vector instruction on addresses
-  auto issue = [&](const int tile, const int buf_off, auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    char* kb = smem + buf_off;
-    const bf16_t* kt = kbase + (int64_t)tile * 64 * rs;   // uniform
-    const bf16_t* vt = kt + v_off;
-#pragma unroll
-    for (int it = 0; it < NDMA; it++) {
-      unsigned vo;
-      if constexpr (FULL) {
-        vo = dma_voff[it];
-      } else {
-        const int last = S - 1 - tile * 64;                     // >= 0: the tile exists
-        const int r = dma_row[it] < last ? dma_row[it] : last;  // rows beyond S re-read row S-1
-        vo = (unsigned)r * rs2 + dma_col2[it];
-      }
-      char* dst = kb + (it * NT + wu * 64) * 16;   // wave-uniform; the hardware adds lane * 16
-      if (dma_on) {
-        dma16_sv(kt, vo, lds_addr(dst));
-        dma16_sv(vt, vo, lds_addr(dst + RT::BYTES));
-      }
-    }
-  };
-  constexpr int BUFB = 2 * RT::BYTES, RINGB = NBUF * BUFB;
-  // compiler-visible vmcnt(0): the Q fragment loads are complete, so the compiler has no reason to drain vmcnt (and
-  // with it the DMA it cannot see) inside the loop
-  __builtin_amdgcn_s_waitcnt(0x0f70);
-#pragma unroll
-  for (int d = 0; d < DIST; d++)
-    if (d < nt) issue(d, d * BUFB, std::false_type{});
-  int cur_off = 0, nxt_off = DIST * BUFB;   // ring offsets of tile t and of tile t + DIST
-
-  // Steady-state iterations (FAST): tile t and the prefetched tile t+2 are both complete 64-key tiles with the full
-  // head dimension, so the loads carry no predicates and the key mask is not even computed; the last (up to three)
-  // iterations take the general path.  The soft-max arithmetic is written on 2-vectors so that the scale/subtract
-  // and the row sums issue as v_pk_fma_f32 / v_pk_add_f32 (the kernel is bound by VALU issue, not by MFMA).
-  const f32x2_t sc2 = {sc, sc};
-  auto iter = [&](const int t, auto fast_tag) {
-    constexpr bool FAST = decltype(fast_tag)::value;
-    const int k0 = t * 64;
-    char* k_lds = smem + cur_off;
-    char* v_lds = k_lds + RT::BYTES;
-    // wait for this wave's DMA of tile t (tiles t+1 .. t+DIST-1 may stay in flight), then the barrier makes every
-    // wave's part of tile t visible and guarantees every wave is done with tile t-1, whose buffer tile t+DIST reuses
-    if (DIST >= 2 && (FAST || t + 1 < nt)) wait_vmcnt<2 * NDMA>();
-    else wait_vmcnt<0>();
-    raw_barrier();
-    if constexpr (FAST) issue(t + DIST, nxt_off, std::true_type{});
-    else if (t + DIST < nt) issue(t + DIST, nxt_off, std::false_type{});
-    cur_off = cur_off + BUFB == RINGB ? 0 : cur_off + BUFB;
-    nxt_off = nxt_off + BUFB == RINGB ? 0 : nxt_off + BUFB;
-    // ---- S^T = K Q^T : sacc[qt][kt] holds S^T[key = kt*16 + 4g + r][q = li] ----
-    f32x4_t sacc[QT][4];
-#pragma unroll
-    for (int qt = 0; qt < QT; qt++)
-#pragma unroll
-      for (int kt = 0; kt < 4; kt++) sacc[qt][kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-      for (int ks = 0; ks < KS; ks++) {
-        const bf16x8_t kf = RT::frag(k_lds, kt * 16 + li, ks * 4 + g);
-#pragma unroll
-        for (int qt = 0; qt < QT; qt++)
-          sacc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], sacc[qt][kt], 0, 0, 0);
-      }
-    // ---- online softmax (query = li, reduced over r, kt in-lane and over g across lanes 16/32 apart) ----
-    bf16x8_t pf[QT][2];
-#pragma unroll
-    for (int qt = 0; qt < QT; qt++) {
-      if constexpr (!FAST) {
-        if (k0 + 64 > S) {  // wave-uniform: only the last tile can hold padded keys
-#pragma unroll
-          for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-              if (k0 + kt * 16 + 4 * g + r >= S) sacc[qt][kt][r] = -INFINITY;
-        }
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) mx = fmaxf(mx, sacc[qt][kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // deferred rescale: keep the old running max unless some row of this wave grew by more than 2^DEFER_LOG2;
-      // P is then bounded by 2^DEFER_LOG2 instead of 1 (bf16 rounding is scale-free, fp32 accumulators have the
-      // headroom), and the O / l rescale -- a full pass over the accumulators -- is skipped on most tiles.
-      const float mcand = mx * sc;   // sc > 0: max commutes with the scaling
-      float mnew = mrun[qt];
-      if (__any(mcand > mrun[qt] + DEFER_LOG2)) {   // wave-uniform; first tile always (mrun = -inf)
-        mnew = fmaxf(mrun[qt], mcand);
-        const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-        lrun[qt] *= alpha;
-        mrun[qt] = mnew;
-#pragma unroll
-        for (int dt = 0; dt < DT; dt++) oacc[qt][dt] *= alpha;
-      }
-      const f32x2_t nm2 = {-mnew, -mnew};
-      f32x2_t ls2 = {0.f, 0.f};
-      f32x2_t pe[4][2];
-#pragma unroll
-      for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-          const f32x2_t sv = {sacc[qt][kt][2 * hf], sacc[qt][kt][2 * hf + 1]};
-          const f32x2_t a = __builtin_elementwise_fma(sv, sc2, nm2);
-          const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          pe[kt][hf] = e;
-          ls2 += e;
-        }
-      lrun[qt] += ls2[0] + ls2[1];
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-        u32x4_t pw;
-        pw[0] = cvt_pk_bf16(pe[2 * c][0][0], pe[2 * c][0][1]);
-        pw[1] = cvt_pk_bf16(pe[2 * c][1][0], pe[2 * c][1][1]);
-        pw[2] = cvt_pk_bf16(pe[2 * c + 1][0][0], pe[2 * c + 1][0][1]);
-        pw[3] = cvt_pk_bf16(pe[2 * c + 1][1][0], pe[2 * c + 1][1][1]);
-        pf[qt][c] = __builtin_bit_cast(bf16x8_t, pw);
-      }
-    }
-    // ---- O^T += V^T P^T : oacc[qt][dt] holds O^T[d = dt*16 + 4g + r][q = li] ----
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int dt = 0; dt < DT; dt++) {
-        const bf16x8_t vf = trf.load(v_lds, c * 32, dt * 16);
-#pragma unroll
-        for (int qt = 0; qt < QT; qt++)
-          oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][c], oacc[qt][dt], 0, 0, 0);
-      }
-  };
-  const int nfull = RT::CAN_FULL ? S / 64 : 0;   // complete 64-key tiles (columns beyond hd are clamped in dma_off)
-  const int t_fast = nfull - DIST > 0 ? nfull - DIST : 0;        // iterations t with tiles t and t+DIST complete
-  int t = 0;
-  for (; t < t_fast; t++) iter(t, std::true_type{});
-  for (; t < nt; t++) iter(t, std::false_type{});
-
-#pragma unroll
-  for (int qt = 0; qt < QT; qt++) {
-    float l = lrun[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const int q = q0 + qt * 16 + li;
-    if (q < S) {
-      const float inv = 1.0f / l;
-      bf16_t* op = o + ((int64_t)b * S + q) * ((int64_t)H * hd) + (int64_t)h * hd;
-#pragma unroll
-      for (int dt = 0; dt < DT; dt++) {
-        const int d = dt * 16 + 4 * g;
-        if (d < hd) {
-          u32x2_t ov;
-          ov[0] = cvt_pk_bf16(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv);
-          ov[1] = cvt_pk_bf16(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv);
-          *(u32x2_t*)(op + d) = ov;
-        }
-      }
-      if (g == 0 && lse2) lse2[((int64_t)b * H + h) * S + q] = mrun[qt] + log2f(l);
-    }
-  }
-}
-
-// =============================================================================================================
-// forward, round 4 ("seeded" soft-max, see SM_HEADROOM above): same tiling, staging and MFMA layout as attn_fwd_kernel
+// forward:  O = softmax(Q K^T * scale) V,  128 queries per workgroup (32 per wave), 64-key tiles; "seeded" soft-max (SM_HEADROOM in
+// attn_common.hpp).  (The round-3 kernel with a per-tile row maximum and a per-score FMA is gone: profiles/r04_abab_attention_biasfuse.md)
 // =============================================================================================================
 // RS = where the soft-max row sums come from: 0 vector adds (v_pk_add_f32 on the fp32 probabilities), 1 the V pad column (head_dim 24),
 // 2 an all-ones A operand: two extra P MFMAs per key tile and 16-row block put sum_k bf16(P) in every row of a 16 x 16 accumulator --
@@ -1024,12 +793,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // =============================================================================================================
 // host entry points
 // =============================================================================================================
-static int g_attn_fwd_qt = 2;   // A/B switch for tools/attn_bench.py (vj_attn_set_variant)
-extern "C" int vj_attn_set_variant(int fwd_qt) {
-  g_attn_fwd_qt = (fwd_qt == 1) ? 1 : 2;
-  return 0;
-}
-
 static int pick_hdp(int64_t hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : (hd <= 80 ? 96 : (hd <= 128 ? 128 : 0))); }
 #define LOG2E 1.4426950408889634f
 
@@ -1065,9 +828,6 @@ static int make_segs(const vj_seg_t* segs, int64_t n_segs, int64_t H, int64_t ro
   return 0;
 }
 
-static int attn_fwd_old(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd, float scale,
-                        hipStream_t stream);
-
 // One launch over n_segs <= 4 segments of one token-major activation: qkv [M, 3*H*hd], o [M, H*hd], lse2 [H*M] (segment i: rows
 // row0_i .. row0_i + B_i*S_i, its lse2 block at H*row0_i laid out [B_i, H, S_i]).
 extern "C" int vj_attn_fwd_segs(const void* qkv, void* o, float* lse2, const vj_seg_t* segs, int64_t n_segs, int64_t H,
@@ -1075,15 +835,6 @@ extern "C" int vj_attn_fwd_segs(const void* qkv, void* o, float* lse2, const vj_
   VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_fwd: head_dim=%ld unsupported (need %%8==0, <=128)", (long)hd);
   VJ_CHECK_ARG(H > 0, "vj_attn_fwd: bad dims");
   const int64_t rs = 3 * H * hd, os = H * hd;
-  if (vj_opt(VJ_OPT_ATTN_SOFTMAX) == 0 || g_attn_fwd_qt != 2) {   // round-3 kernels: one launch per segment
-    VJ_CHECK_ARG(segs != nullptr && n_segs >= 0, "vj_attn_fwd_segs: bad segment list");
-    for (int64_t i = 0; i < n_segs; i++) {
-      const int rc = attn_fwd_old((const bf16_t*)qkv + segs[i].row0 * rs, (bf16_t*)o + segs[i].row0 * os,
-                                  lse2 ? lse2 + H * segs[i].row0 : nullptr, segs[i].B, segs[i].S, H, hd, scale, stream);
-      if (rc) return rc;
-    }
-    return 0;
-  }
   AttnSegs sg;
   int64_t nblk = 0;
   if (int rc = make_segs(segs, n_segs, H, 128, &sg, &nblk, "vj_attn_fwd")) return rc;
@@ -1091,20 +842,19 @@ extern "C" int vj_attn_fwd_segs(const void* qkv, void* o, float* lse2, const vj_
   // scale < 0: the q part of qkv ALREADY carries |scale| * log2(e) (the qkv GEMM applied it before its bf16 rounding, epilogue 4
   // of vj_gemm_bf16_nt): the kernels' own factor becomes 1 (scale_frag(x, 1) is the identity)
   const float sc = scale < 0.f ? 1.0f : scale * LOG2E;
-  // round-4 kernels (seeded soft-max); head_dim 24: row sums on the pad column
+  // row sums from the matrix pipe: head_dim 24 on the V image's pad column (RS = 1), the other head sizes from an all-ones operand (RS = 2);
+  // the vector-add form (RS = 0) of round 3 is no longer instantiated (profiles/r04_abab_rowsums.md)
 #define VJ_FWD_SM(HDPV, NB, RSV)                                                                                      \
   hipLaunchKernelGGL((attn_fwd_sm_kernel<HDPV, 2, NB, RSV>), dim3((unsigned)nblk), dim3(256), 0, stream,               \
                      (const bf16_t*)qkv, (bf16_t*)o, lse2, sg, (int)H, (int)hd, sc)
-  const int psum = vj_opt(VJ_OPT_ATTN_PSUM);   // 0: row sums on the vector pipe; 1: pad column (hd 24) / ones-operand MFMA (others)
   switch (pick_hdp(hd)) {
     case 32:
-      if (hd == 24 && psum != 0) VJ_FWD_SM(32, 3, 1);
-      else if (psum != 0) VJ_FWD_SM(32, 3, 2);
-      else VJ_FWD_SM(32, 3, 0);
+      if (hd == 24) VJ_FWD_SM(32, 3, 1);
+      else VJ_FWD_SM(32, 3, 2);
       break;
-    case 64: if (psum != 0) VJ_FWD_SM(64, 2, 2); else VJ_FWD_SM(64, 2, 0); break;
-    case 96: if (psum != 0) VJ_FWD_SM(96, 2, 2); else VJ_FWD_SM(96, 2, 0); break;
-    default: if (psum != 0) VJ_FWD_SM(128, 2, 2); else VJ_FWD_SM(128, 2, 0);
+    case 64: VJ_FWD_SM(64, 2, 2); break;
+    case 96: VJ_FWD_SM(96, 2, 2); break;
+    default: VJ_FWD_SM(128, 2, 2);
   }
 #undef VJ_FWD_SM
   VJ_LAUNCH_CHECK("vj_attn_fwd");
@@ -1116,44 +866,6 @@ extern "C" int vj_attn_fwd(const void* qkv, void* o, float* lse2, int64_t B, int
   VJ_CHECK_ARG(B >= 0 && S >= 0 && H > 0, "vj_attn_fwd: bad dims");
   const vj_seg_t one = {0, B, S};
   return vj_attn_fwd_segs(qkv, o, lse2, &one, 1, H, hd, scale, stream);
-}
-
-static int attn_fwd_old(const void* qkv, void* o, float* lse2, int64_t B, int64_t S, int64_t H, int64_t hd, float scale,
-                        hipStream_t stream) {
-  VJ_CHECK_ARG(hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_fwd: head_dim=%ld unsupported (need %%8==0, <=128)", (long)hd);
-  VJ_CHECK_ARG(B >= 0 && S >= 0 && H > 0, "vj_attn_fwd: bad dims");
-  if (B * S == 0) return 0;
-  const int nqb = (int)cdiv64(S, 128);
-  const int64_t nblk = B * H * nqb;
-  VJ_CHECK_ARG(nblk < (1ll << 31), "vj_attn_fwd: grid too large");
-  const float sc = scale < 0.f ? 1.0f : scale * LOG2E;   // (scale < 0: q pre-scaled, see vj_attn_fwd_segs)
-  // QT = 16-row query tiles per wave (QT = 1: 8 waves / workgroup, half the registers per wave).  Measured on
-  // MI355X: QT = 2 is faster or equal for every head size (the kernel is bound by VALU issue, not by occupancy).
-#define VJ_FWD(HDPV, QTV, NB)                                                                                        \
-  hipLaunchKernelGGL((attn_fwd_kernel<HDPV, QTV, NB>), dim3((unsigned)nblk), dim3(8 * 64 / QTV), 0, stream,            \
-                     (const bf16_t*)qkv, (bf16_t*)o, lse2, (int)B, (int)S, (int)H, (int)hd, sc, nqb)
-  const int qt_sel = g_attn_fwd_qt;
-  // ring depth: 2 buffers for hd <= 64 measured equal or faster than 3 (396 vs 408 us on the ViT-L target shape) and
-  // leaves 32 KB of LDS, i.e. the forward can share a CU with other work; VJ_ATTN_NBUF=3 selects the deeper ring
-  static const int nb_env = [] { const char* e = getenv("VJ_ATTN_NBUF"); return e ? atoi(e) : 0; }();
-  switch (pick_hdp(hd)) {
-    case 32:
-      if (qt_sel != 2) VJ_FWD(32, 1, 3);
-      else if (nb_env == 2) VJ_FWD(32, 2, 2);
-      else VJ_FWD(32, 2, 3);
-      break;
-    case 64:
-      if (qt_sel != 2) VJ_FWD(64, 1, 3);
-      else if (nb_env == 3) VJ_FWD(64, 2, 3);
-      else VJ_FWD(64, 2, 2);
-      break;
-    case 96: VJ_FWD(96, 2, 2); break;   // hd 65..80 (ViT-H: 80): 3 k-steps, 5 output tiles instead of the 128 class' 4 / 8
-    default:
-      if (qt_sel == 2) VJ_FWD(128, 2, 2); else VJ_FWD(128, 1, 2);
-  }
-#undef VJ_FWD
-  VJ_LAUNCH_CHECK("vj_attn_fwd");
-  return 0;
 }
 
 extern "C" int64_t vj_attn_bwd_ws_bytes(int64_t B, int64_t S, int64_t H) { return B * S * H * 4; }
@@ -1169,17 +881,10 @@ extern "C" int64_t vj_attn_bwd_segs_ws_bytes(const vj_seg_t* segs, int64_t n_seg
   return rows_end * H * 4;
 }
 
-// dK/dV tiling of the current options: 16-key tiles per wave (the column-partial row count depends on it)
-static int dkdv_kt(int64_t hd) {
-  const int kt_opt = vj_opt(VJ_OPT_ATTN_DKDV_KT);
-  switch (pick_hdp(hd)) {
-    case 32: return kt_opt == 1 ? 1 : (kt_opt == 4 ? 4 : 2);
-    case 64: return kt_opt == 2 ? 2 : 1;
-    default: return 1;
-  }
-}
-// dQ tiling of the current options: 16-query tiles per wave (option attn_dq_qw: 0 = 2 everywhere; 4 = four at head_dim <= 32)
-static int dq_qw(int64_t hd) { return (vj_opt(VJ_OPT_ATTN_DQ_QW) == 4 && pick_hdp(hd) == 32) ? 4 : 2; }
+// dK/dV tiling: 16-key tiles per wave (32 keys at head_dim <= 32: every Q / dO fragment and transposed read serves two key tiles; 64 keys per
+// wave and 64 queries per wave in the dQ kernel were options in round 5: -0.09 / +0.23 ms per step, profiles/r05_attn_tiles.md)
+static int dkdv_kt(int64_t hd) { return pick_hdp(hd) == 32 ? 2 : 1; }
+static int dq_qw(int64_t) { return 2; }
 // rows of the column-partial matrices vj_attn_bwd_colsum writes for one [B, S] segment: colq [rows_q][H*hd], colkv [rows_kv][2*H*hd]
 extern "C" int vj_attn_bwd_colsum_rows(int64_t B, int64_t S, int64_t hd, int64_t* rows_q, int64_t* rows_kv) {
   VJ_CHECK_ARG(rows_q != nullptr && rows_kv != nullptr && hd % 8 == 0 && pick_hdp(hd) != 0, "vj_attn_bwd_colsum_rows: bad arguments");
@@ -1217,33 +922,21 @@ extern "C" int vj_attn_bwd_segs(const void* qkv, const void* o, const void* dout
   const float kscale = pre ? 1.0f / LOG2E : sabs;
   // dQ first: it also produces delta[b,h,s] = dO . O for the dK/dV kernel behind it on the same stream.
   // dK/dV: KTV 16-key tiles per wave (option attn_dkdv_kt: 0 = per head-dim class, 1 / 2 forced)
-#define VJ_BWD_LAUNCH(HDPV, KTV, SMV)                                                                              \
+#define VJ_BWD_LAUNCH(HDPV, KTV)                                                                                   \
   do {                                                                                                             \
-    if (HDPV == 32 && qw == 4)                                                                                     \
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV == 32 ? 32 : HDPV, SMV, HDPV == 32 ? 4 : 2>), dim3((unsigned)gq), dim3(256), 0, stream, \
-                         (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sq, \
-                         (int)H, (int)hd, sc, sabs, colq);                                                         \
-    else                                                                                                           \
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, SMV, 2>), dim3((unsigned)gq), dim3(256), 0, stream,              \
-                         (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sq, \
-                         (int)H, (int)hd, sc, sabs, colq);                                                         \
-    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV, SMV>), dim3((unsigned)gk), dim3(256), 0, stream,            \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDPV, true, 2>), dim3((unsigned)gq), dim3(256), 0, stream,               \
+                       (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sq,   \
+                       (int)H, (int)hd, sc, sabs, colq);                                                           \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDPV, KTV, true>), dim3((unsigned)gk), dim3(256), 0, stream,           \
                        (const bf16_t*)qkv, (const bf16_t*)dout, lse2, delta, (bf16_t*)dqkv, sk, (int)H, (int)hd,    \
                        sc, kscale, colkv);                                                                         \
   } while (0)
-#define VJ_BWD_SM(HDPV, KTV)                                     \
-  do {                                                           \
-    if (sm) VJ_BWD_LAUNCH(HDPV, KTV, true);                      \
-    else VJ_BWD_LAUNCH(HDPV, KTV, false);                        \
-  } while (0)
-  const bool sm = vj_opt(VJ_OPT_ATTN_SOFTMAX) != 0;
   switch (pick_hdp(hd)) {
-    case 32: if (kt == 1) VJ_BWD_SM(32, 1); else if (kt == 4) VJ_BWD_SM(32, 4); else VJ_BWD_SM(32, 2); break;
-    case 64: if (kt == 2) VJ_BWD_SM(64, 2); else VJ_BWD_SM(64, 1); break;
-    case 96: VJ_BWD_SM(96, 1); break;
-    default: VJ_BWD_SM(128, 1);
+    case 32: VJ_BWD_LAUNCH(32, 2); break;
+    case 64: VJ_BWD_LAUNCH(64, 1); break;
+    case 96: VJ_BWD_LAUNCH(96, 1); break;
+    default: VJ_BWD_LAUNCH(128, 1);
   }
-#undef VJ_BWD_SM
 #undef VJ_BWD_LAUNCH
   VJ_LAUNCH_CHECK("vj_attn_bwd");
   return 0;

@@ -341,7 +341,7 @@ static int blocks_fwd_impl(const vj_block_t* blocks, const vj_lnfold_t* folds, i
       for (int k = 0; k < L.n_gap; k++) CH(poison_gap((char*)ws + li * L.total + L.gap[k], stream));
     if (!save) CH(poison_gap((char*)ws + L.total + al256(M * D * 2), stream));
   }
-  const bool merge_segs = n_segs > 1 && n_segs <= 4 && vj_opt(VJ_OPT_ATTN_MERGE) != 0;
+  const bool merge_segs = n_segs > 1 && n_segs <= 4;   // all masks of the batch in ONE attention launch (profiles/r04_abab_attn_merge.md)
   const bool qpre = vj_opt(VJ_OPT_ATTN_SOFTMAX) == 2 && (3 * D) % 12 == 0;
   const float ascale = qpre ? -scale : scale;   // negative: "q is pre-scaled" (vj_attn_fwd_segs)
   char* base = (char*)ws;
@@ -669,7 +669,7 @@ extern "C" int vj_blocks_bwd(const vj_block_t* blocks, int64_t n_blocks, const v
       if (rows_q > L.colp_attn_rows || rows_kv > L.colp_attn_rows) qkv_fused = false;
     }
     int64_t off_q = 0, off_kv = 0;
-    const bool merge_segs = n_segs > 1 && n_segs <= 4 && vj_opt(VJ_OPT_ATTN_MERGE) != 0;
+    const bool merge_segs = n_segs > 1 && n_segs <= 4;
     // as the FORWARD stored q: flags bit 3 set -> bit 2 says whether q is pre-scaled (the caller recorded the mode its vj_blocks_fwd
     // call used); otherwise the option is read again, which is only right if it did not change since that forward
     const bool qpre_b = (flags & 8) ? (flags & 4) != 0 : (vj_opt(VJ_OPT_ATTN_SOFTMAX) == 2 && (3 * D) % 12 == 0);

@@ -9,8 +9,7 @@
 // Structure: 128x128 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles; K-tile 64 (32 as a
 // fallback when K % 64 != 0); two LDS buffers; ONE barrier per K-tile; tile t+1 is staged while tile t is
 // multiplied.  Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip) with the XOR swizzle applied on the
-// per-lane SOURCE address (the DMA destination is lane-linear), or register staging (same LDS image) when the
-// caller asks for it.  The MFMA is issued with swapped operands (D = Bfrag x Afrag) so each lane owns four
+// per-lane SOURCE address (the DMA destination is lane-linear).  The MFMA is issued with swapped operands (D = Bfrag x Afrag) so each lane owns four
 // CONSECUTIVE output columns: 8-byte bf16 / 16-byte fp32 epilogue accesses for C, bias, residual and aux.
 // Workgroup ids are remapped so every XCD (private L2) works on a contiguous band of tiles.
 #include "gemm_common.hpp"
@@ -32,9 +31,9 @@ __device__ __forceinline__ int swz_of(int row) {
 }
 
 // ---- staging: one 128 x BK bf16 operand tile -> LDS (lane-linear image, source-side swizzle) ----
-template <int BK, bool GLDS, int ROWS, int NT>
+template <int BK, int ROWS, int NT>
 __device__ __forceinline__ void stage_issue(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t rows,
-                                            int64_t k0, char* lds_tile, int tid, int wave_u, u32x4_t* regs) {
+                                            int64_t k0, char* lds_tile, int tid, int wave_u) {
   constexpr int CPR = BK / 8;                  // 16-byte chunks per tile row
   constexpr int NIT = (ROWS * CPR) / NT;       // chunks per thread
 #pragma unroll
@@ -45,24 +44,9 @@ __device__ __forceinline__ void stage_issue(const bf16_t* __restrict__ G, int64_
     int64_t gr = row0 + row;
     gr = gr < rows ? gr : rows - 1;            // clamp: tail rows are never stored
     const bf16_t* src = G + gr * ld + k0 + c * 8;
-    if constexpr (GLDS) {
-      char* dst = lds_tile + (j * NT + wave_u * 64) * 16;  // wave-uniform base; HW adds lane*16
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    } else {
-      regs[j] = *(const u32x4_t*)src;
-    }
-  }
-}
-
-template <int BK, int ROWS, int NT>
-__device__ __forceinline__ void stage_commit(char* lds_tile, int tid, const u32x4_t* regs) {
-  constexpr int CPR = BK / 8;
-  constexpr int NIT = (ROWS * CPR) / NT;
-#pragma unroll
-  for (int j = 0; j < NIT; j++) {
-    const int q = j * NT + tid;
-    *(u32x4_t*)(lds_tile + q * 16) = regs[j];
+    char* dst = lds_tile + (j * NT + wave_u * 64) * 16;  // wave-uniform base; HW adds lane*16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
 }
 
@@ -75,10 +59,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // barrier).  NS > 2 keeps NS-2 stages of LDS-DMA in flight ACROSS the per-K-tile barrier with a counted
 // s_waitcnt vmcnt (never 0 in steady state) and a raw s_barrier, which is what hides HBM/L2 latency when the
 // K loop is short (K = 1024 / 384 in this model).
-template <int BK, int NS, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
+template <int BK, int NS, int EPI, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(GLDS || NS == 2, "register staging supports only the double buffer");
   constexpr int NT = WM * WN * 64;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int CPR = BK / 8;
@@ -113,7 +96,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_nt_
   const int nk_all = (int)(p.K / BK);
   const int kt0 = slice * p.ktiles_per;
   const int kt1 = (kt0 + p.ktiles_per) < nk_all ? (kt0 + p.ktiles_per) : nk_all;
-  u32x4_t ra[NIT_A], rb[NIT_B];
 
   // fragment read offsets (bytes inside a tile), constant across K-tiles
   const int frow = lane & 15, fg = lane >> 4;
@@ -140,29 +122,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_nt_
   for (int st = 0; st < NS - 1; st++) {
     if (st < nkt) {
       char* slot = smem + st * STAGE_BYTES;
-      stage_issue<BK, GLDS, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)(kt0 + st) * BK, slot, tid, wave_u, ra);
-      stage_issue<BK, GLDS, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)(kt0 + st) * BK, slot + A_BYTES, tid, wave_u, rb);
-      if constexpr (!GLDS) {
-        stage_commit<BK, BM, NT>(slot, tid, ra);
-        stage_commit<BK, BN, NT>(slot + A_BYTES, tid, rb);
-      }
+      stage_issue<BK, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)(kt0 + st) * BK, slot, tid, wave_u);
+      stage_issue<BK, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)(kt0 + st) * BK, slot + A_BYTES, tid, wave_u);
     }
   }
 
   for (int it = 0; it < nkt; it++) {
     char* cur = smem + (it % NS) * STAGE_BYTES;
     char* nxt = smem + ((it + NS - 1) % NS) * STAGE_BYTES;
-    if constexpr (GLDS) {
-      // stage `it` must have landed; in steady state NS-2 younger stages stay in flight
-      if (it + NS - 2 <= nkt - 1) wait_vmcnt<(NS - 2) * LOADS>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();  // every wave's DMA for stage `it` landed; every wave finished reading stage it-1
-    } else {
-      __syncthreads();
-    }
+    // stage `it` must have landed; in steady state NS-2 younger stages stay in flight
+    if (it + NS - 2 <= nkt - 1) wait_vmcnt<(NS - 2) * LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's DMA for stage `it` landed; every wave finished reading stage it-1
     if (it + NS - 1 < nkt) {
-      stage_issue<BK, GLDS, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)(kt0 + it + NS - 1) * BK, nxt, tid, wave_u, ra);
-      stage_issue<BK, GLDS, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)(kt0 + it + NS - 1) * BK, nxt + A_BYTES, tid, wave_u, rb);
+      stage_issue<BK, BM, NT>(p.A, p.lda, m0, p.M, (int64_t)(kt0 + it + NS - 1) * BK, nxt, tid, wave_u);
+      stage_issue<BK, BN, NT>(p.B, p.ldb, n0, p.N, (int64_t)(kt0 + it + NS - 1) * BK, nxt + A_BYTES, tid, wave_u);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ks++) {
@@ -176,12 +150,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_nt_
 #pragma unroll
         for (int j = 0; j < FN; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    if constexpr (!GLDS) {
-      if (it + 1 < nkt) {  // other buffer: nobody reads it until the next barrier
-        stage_commit<BK, BM, NT>(nxt, tid, ra);
-        stage_commit<BK, BN, NT>(nxt + A_BYTES, tid, rb);
-      }
     }
   }
 
@@ -216,13 +184,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
   }
 }
 
-template <int BK, int NS, int EPI, bool GLDS, int BM, int BN, int WM, int WN>
+template <int BK, int NS, int EPI, int BM, int BN, int WM, int WN>
 static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t stream) {
   constexpr int smem = NS * (BM + BN) * BK * 2;
   // function-local static with an initialiser: set exactly once, thread-safe (the C ABI is re-entrant)
   static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
   attr_once([] {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, NS, EPI, GLDS, BM, BN, WM, WN>,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BK, NS, EPI, BM, BN, WM, WN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   });
   GemmArgs b = a;
@@ -244,7 +212,7 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
   b.ktiles_per = (nk + b.splitk - 1) / b.splitk;
   b.splitk = (nk + b.ktiles_per - 1) / b.ktiles_per;  // no empty slices
   const int nblk = b.tiles_m * b.tiles_n * b.splitk;
-  hipLaunchKernelGGL((gemm_nt_kernel<BK, NS, EPI, GLDS, BM, BN, WM, WN>), dim3(nblk), dim3(WM * WN * 64), smem, stream,
+  hipLaunchKernelGGL((gemm_nt_kernel<BK, NS, EPI, BM, BN, WM, WN>), dim3(nblk), dim3(WM * WN * 64), smem, stream,
                      b);
   VJ_LAUNCH_CHECK("vj_gemm_bf16_nt");
   if (b.splitk > 1) {
@@ -258,29 +226,22 @@ static int launch_gemm(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_
   return 0;
 }
 
-// flags: bit0 = register-staged operands (A/B testing); bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256);
-//        bits 6-7 = pipeline (0 auto, 1 = BK64 double buffer, 2 = BK32 4-stage ring with counted vmcnt,
-//                   3 = 256x256 staggered 8-phase schedule, gemm8.hip)
+// flags: bits 4-5 = tile config (0 auto, 1 = 128x128, 2 = 256x256); bits 6-7 = pipeline (0 auto, 1 = BK64 double buffer, 2 = BK32 4-stage
+//        ring with counted vmcnt, 3 = 256x256 staggered 8-phase schedule, gemm8.hip / gemm8p.hip); bit 8 = the 4-wave 256x128 kernel with two
+//        workgroups per CU (gemm4w.hip: single-stream inference).  (Register-staged operands, a 256x128 BK32 ring and a persistent form of
+//        the 4-wave kernel existed through round 5; all measured slower in the step: profiles/r03_abab_switches.md, r05_gemm_4wp.md.)
 int vj_gemm_launch_8phase(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);  // gemm8.hip
 int vj_gemm_launch_4w(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream);      // gemm4w.hip
 int vj_gemm_launch_8phase_persist(const GemmArgs& a, int epilogue, hipStream_t stream);                        // gemm8p.hip (-100: n/a)
-int vj_gemm_launch_4wp(const GemmArgs& a, int epilogue, hipStream_t stream);                                   // gemm4w.hip (-100: n/a)
 
 template <int EPI>
 static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_bytes, hipStream_t stream) {   // (flags: by value, edited below)
-  const bool reg_staged = (flags & 1) != 0;
   int cfg = (flags >> 4) & 3;
   int pipe = (flags >> 6) & 3;
   const bool is_wgrad = (EPI == EPI_F32 && ws != nullptr);
-  if (a.lnf_rs != nullptr) flags &= ~0x300;   // the 4-wave kernels carry no folded-LayerNorm epilogue
-  // bit 9 (round 5): the PERSISTENT form of the 4-wave kernel (two workgroups per CU walking tile lists); bit-identical outputs
-  if ((flags & 0x200) && !is_wgrad && !reg_staged) {
-    const int rc = vj_gemm_launch_4wp(a, EPI, stream);
-    if (rc != -100) return rc;
-    flags &= ~0x200;
-  }
+  if (a.lnf_rs != nullptr) flags &= ~0x100;   // the 4-wave kernel carries no folded-LayerNorm epilogue
   // bit 8: the 4-wave 256x128 kernel with two workgroups per CU (gemm4w.hip)
-  if ((flags & 0x100) && a.K % 64 == 0 && !reg_staged) return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
+  if ((flags & 0x100) && a.K % 64 == 0) return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
   if (pipe == 0 && cfg == 0) {
     // measured on the ViT-L step shapes (tools/gemm_bench.py): the staggered 8-phase 256x256 kernel wins on every
     // forward / dgrad shape with >= ~90 tiles; split-K wgrads (few tiles, long K) stay on 128x128 with 2 workgroups
@@ -293,18 +254,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     // VJ_GEMM_4W=1 (all forward / dgrad GEMMs), meant for single-stream use (inference, profiling).
     const int64_t t4w = cdiv64(a.M, 256) * cdiv64(a.N, 128);
     const int use_4w = a.lnf_rs != nullptr ? 0 : vj_opt(VJ_OPT_GEMM_4W);
-    if (use_4w == 1 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 64)
-      return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
-    // 2: only where a 256-wide tile wastes a third of its columns (N = 384: the predictor's proj / fc2 / dgrad outputs)
-    if (use_4w == 2 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 64 && a.N % 256 == 128 && a.N < 512)
-      return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
-    // 3 (round 5): the persistent 4-wave kernel wherever the persistent 8-phase kernel would run; 4: only for K <= 512 (the predictor's
-    // short-K shapes, where the per-tile fixed cost is ~45 % of a tile); 5: only for N <= 1152 and K <= 1024 (+ the N = K = 1024 projections)
-    if (use_4w >= 3 && !is_wgrad && a.K % 64 == 0 && !reg_staged && t4w >= 180 &&
-        (use_4w == 3 || (use_4w == 4 && a.K <= 512) || (use_4w == 5 && a.K <= 1024 && a.N <= 1152))) {
-      const int rc = vj_gemm_launch_4wp(a, EPI, stream);
-      if (rc != -100) return rc;
-    }
+    if (use_4w == 1 && !is_wgrad && a.K % 64 == 0 && t4w >= 64) return vj_gemm_launch_4w(a, EPI, ws, ws_bytes, stream);
     const int64_t t256 = cdiv64(a.M, 256) * cdiv64(a.N, 256);
     if (!is_wgrad && a.K % 64 == 0 && t256 >= 90) pipe = 3;
     if (is_wgrad && a.K % 64 == 0 && t256 >= 40) pipe = 3;   // qkv/fc1/fc2 wgrads: 8-phase + split-K (0.97-1.08 vs 0.78-0.96 PF)
@@ -312,8 +262,7 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
   if (cfg == 0) cfg = 1;
   if (pipe == 0) pipe = 1;       // BK64 double buffer (beats the BK32 ring on every step shape)
   if (a.K % 64 != 0) pipe = 2;   // K % 32 only fits the BK32 pipeline
-  if (cfg == 3) pipe = 2;
-  if (pipe == 3 && a.K % 64 == 0 && !reg_staged) {
+  if (pipe == 3 && a.K % 64 == 0) {
     // persistent variant (gemm8p.hip): one workgroup per CU walks its tiles, next tile's operands prefetched under the
     // current tile, epilogue stores drained under the next K loop; bit-identical outputs.  Run-time option "gemm_persist".
     if (EPI != EPI_F32 && vj_opt(VJ_OPT_GEMM_PERSIST) != 0 && !(a.dbg & 2)) {
@@ -325,17 +274,11 @@ static int dispatch_gemm(const GemmArgs& a, int flags, void* ws, int64_t ws_byte
     if (cfg == 1 && a.M >= 256 && a.N >= 256) cfg = 2;
   }
   if (pipe == 3) pipe = 1;
-  if (reg_staged) {
-    if (a.K % 64 != 0) return launch_gemm<32, 2, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
-    return cfg == 2 ? launch_gemm<64, 2, EPI, false, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
-                    : launch_gemm<64, 2, EPI, false, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
-  }
   if (pipe == 1)
-    return cfg == 2 ? launch_gemm<64, 2, EPI, true, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
-                    : launch_gemm<64, 2, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
-  if (cfg == 3) return launch_gemm<32, 3, EPI, true, 256, 128, 2, 2>(a, ws, ws_bytes, stream);
-  return cfg == 2 ? launch_gemm<32, 4, EPI, true, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
-                  : launch_gemm<32, 4, EPI, true, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
+    return cfg == 2 ? launch_gemm<64, 2, EPI, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
+                    : launch_gemm<64, 2, EPI, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
+  return cfg == 2 ? launch_gemm<32, 4, EPI, 256, 256, 2, 4>(a, ws, ws_bytes, stream)
+                  : launch_gemm<32, 4, EPI, 128, 128, 2, 2>(a, ws, ws_bytes, stream);
 }
 
 static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
@@ -370,11 +313,9 @@ static int gemm_entry(const void* A, int64_t lda, const void* B, int64_t ldb, vo
   a.dbg = vj_opt(VJ_OPT_GEMM_DBG);
   a.zero_row = nullptr;
   a.colpart = nullptr;
-  a.gelu_lp = vj_opt(VJ_OPT_GELU_POLY);
   a.raster = 0;
   a.lnf_rs = lnf_rs;
   a.lnf_c = lnf_c;
-  a.dyn_slot = -1;
   a.qscale = qscale;
   a.qcols = qscale != 0.f ? N / 3 : 0;
   switch (epilogue) {
@@ -423,7 +364,7 @@ extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const vo
   VJ_CHECK_ARG(fused != nullptr, "vj_gemm_bf16_nt_dgelu_colsum: null `fused`");
   *fused = 0;
   const int64_t t256 = cdiv64(M, 256) * cdiv64(N, 256);
-  if (colpart != nullptr && (flags & ~0x200) == 0 && M > 0 && N > 0 && K > 0 && K % 64 == 0 && t256 >= 90 && (vj_opt(VJ_OPT_GEMM_4W) == 0 || vj_opt(VJ_OPT_GEMM_4W) >= 3) &&
+  if (colpart != nullptr && flags == 0 && M > 0 && N > 0 && K > 0 && K % 64 == 0 && t256 >= 90 && vj_opt(VJ_OPT_GEMM_4W) == 0 &&
       vj_opt(VJ_OPT_GEMM_PERSIST) != 0 && vj_opt(VJ_OPT_GEMM_DBG) == 0 && aux_in != nullptr && lda % 8 == 0 && ldb % 8 == 0 &&
       lda >= K && ldb >= K && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ldc % 4 == 0 && ldc >= N &&
       ldaux % 4 == 0 && N % 4 == 0 && (uintptr_t)C % 8 == 0) {
@@ -441,11 +382,9 @@ extern "C" int vj_gemm_bf16_nt_dgelu_colsum(const void* A, int64_t lda, const vo
     a.qscale = 0.f;
     a.qcols = 0;
     a.colpart = colpart;
-    a.gelu_lp = 0;
     a.raster = 0;
     a.lnf_rs = nullptr;
     a.lnf_c = nullptr;
-    a.dyn_slot = -1;
     const int rc = vj_gemm_launch_8phase_persist(a, EPI_DGELU, stream);
     if (rc != -100) {
       *fused = (rc == 0);

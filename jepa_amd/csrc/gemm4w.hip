@@ -301,56 +301,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_4w_kernel(GemmArgs p) {
   gemm_epilogue<EPI, 8, 4, /*INTERIOR_VARIANT=*/(EPI == EPI_F32), false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, slice);
 }
 
-// ---- persistent form (round 5, flags bit 9 / option gemm_4w = 3: the experiment VERDICT r4 item 1 asks for) -----------------
-// The same K loop and epilogue, but a workgroup WALKS a list of tiles (XCD-banded order of gemm8p.hip, edge tiles shifted inside
-// the matrix so that every tile is an interior tile) instead of ending after one: no launch boundary between tiles, the
-// epilogue's stores are issued and not waited for (the next tile's first counted vmcnt is merely conservative while they
-// drain), and the two workgroups of a CU drift out of phase, so one converts / stages / stores while the other is in its K
-// loop -- the overlap a single 8-wave workgroup cannot have (one accumulator set, all registers taken).  Outputs are
-// bit-identical to the one-tile kernel (same K loop, same epilogue arithmetic; rows / columns shared by a shifted tile and
-// its neighbour are written twice with identical bits).  No cross-tile operand prefetch: the prologue latency of a tile is
-// covered by the partner workgroup, which is the point of the experiment.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_4wp_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave_u >> 1, wn = wave_u & 1;
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int G = (int)gridDim.x, bid = (int)blockIdx.x;
-  const int xcd = bid & 7, pos = bid >> 3;
-  const int qx = ntile >> 3, rx = ntile & 7;
-  const int band0 = xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx;
-  const int band_n = qx + (xcd < rx ? 1 : 0);
-  const int wgs_x = (G - xcd + 7) >> 3;
-  const int nk = (int)(p.K / W4_BK);
-  for (int li = pos; li < band_n; li += wgs_x) {
-    int tm, tn;
-    tile_of_raster(band0 + li, p.tiles_m, p.tiles_n, p.raster, tm, tn);
-    int64_t m0 = (int64_t)tm * W4_BM, n0 = (int64_t)tn * W4_BN;
-    m0 = m0 + W4_BM <= p.M ? m0 : p.M - W4_BM;
-    n0 = n0 + W4_BN <= p.N ? n0 : p.N - W4_BN;
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    // thread id through a VOLATILE asm per tile: the K loop's per-lane offsets (fragment bases, DMA offsets) are then recomputed
-    // for every tile instead of being hoisted out of the tile loop, where they would stay live across the epilogue (spills)
-    int tid_t;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(tid_t) : "v"(tid));
-    const int lane_t = tid_t & 63;
-    k_loop_4w<false>(p, smem, acc, m0, n0, 0, nk, tid_t, wave_u, wm, wn, lane_t & 15, lane_t >> 4);   // ends with vmcnt(0) + barrier: the ring is free
-    // lane id re-derived through a VOLATILE asm: the epilogue's address arithmetic is recomputed per tile instead of being
-    // hoisted out of the tile loop into registers that would then be live across the K loop
-    int elane;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
-    const int efrow = elane & 15, efg = elane >> 4;
-    if (!gemm_epilogue_try_staged<EPI, 8, false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane, smem + wave_u * 16384))
-      gemm_epilogue<EPI, 8, 4, false, false>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, 0);
-    bar4();   // every wave has read its staging region back: the next tile's prologue may overwrite the ring
-  }
-}
+// (A persistent form of this kernel -- two workgroups per CU walking tile lists -- was built in round 5: bit-identical, slower on every
+//  shape and policy, profiles/r05_gemm_4wp.md.)
 
 __global__ void splitk_reduce_kernel(const float4* ws, float* out, int64_t M, int64_t N, int64_t ldc, int S,
                                      float alpha, float beta);   // gemm.hip
@@ -397,61 +349,6 @@ static int launch4w(const GemmArgs& a, void* ws, int64_t ws_bytes, hipStream_t s
   return 0;
 }
 
-static int g_4wp_cus = 0;
-
-template <int EPI>
-static int launch4wp(const GemmArgs& a, hipStream_t stream) {
-  constexpr int smem = W4_SLOTS * W4_PART;
-  static VjPerDeviceOnce attr_once;
-  attr_once([] {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_4wp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  });
-  GemmArgs b = a;
-  b.tiles_m = (int)cdiv64(a.M, W4_BM);
-  b.tiles_n = (int)cdiv64(a.N, W4_BN);
-  b.splitk = 1;
-  b.ws = nullptr;
-  b.ktiles_per = (int)(a.K / W4_BK);
-  b.raster = 256 + 8;   // column groups of eight 128-wide tiles: the 64 concurrent tiles of an XCD are 8 rows x 8 columns (1024 columns of B)
-  const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
-  const int64_t slots = 2 * (int64_t)g_4wp_cus;
-  const int64_t rounds = cdiv64(tiles, slots);
-  const int64_t band = cdiv64(tiles, 8);
-  int64_t per_xcd = cdiv64(band, rounds);
-  if (per_xcd * 8 > slots) per_xcd = slots / 8;
-  hipLaunchKernelGGL(gemm_nt_4wp_kernel<EPI>, dim3((unsigned)(per_xcd * 8)), dim3(256), smem, stream, b);
-  VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 4-wave)");
-  return 0;
-}
-
-// persistent two-workgroups-per-CU form: -100 when it does not apply (the caller keeps its previous choice)
-int vj_gemm_launch_4wp(const GemmArgs& a, int epilogue, hipStream_t stream) {
-  if (g_4wp_cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      return -100;
-    g_4wp_cus = n;
-  }
-  if (epilogue == EPI_F32 || a.M < W4_BM || a.N < W4_BN || a.K % W4_BK != 0 || a.K < 3 * W4_BK || a.lnf_rs != nullptr) return -100;
-  if (a.lda >= (1 << 23) || a.ldb >= (1 << 23) || a.colpart != nullptr) return -100;
-  auto overlaps = [&](const void* q, int64_t ld) {   // shifted edge tiles rewrite their neighbours' outputs: inputs must not alias C
-    if (q == nullptr) return false;
-    const char* c0 = (const char*)a.C;
-    const char* c1 = c0 + (a.M * a.ldc) * 2;
-    const char* q0 = (const char*)q;
-    const char* q1 = q0 + (a.M * ld) * 2;
-    return q0 < c1 && c0 < q1;
-  };
-  if (overlaps(a.res, a.ldr) || overlaps(a.aux_in, a.ldaux) || overlaps(a.A, a.lda)) return -100;
-  switch (epilogue) {
-    case EPI_BF16: return launch4wp<EPI_BF16>(a, stream);
-    case EPI_GELU: return launch4wp<EPI_GELU>(a, stream);
-    case EPI_DGELU: return launch4wp<EPI_DGELU>(a, stream);
-    default: return -100;
-  }
-}
-
-// entry used by gemm.hip's dispatcher (flags bit 8 / the auto policy); requires K % 64 == 0
 int vj_gemm_launch_4w(const GemmArgs& a, int epilogue, void* ws, int64_t ws_bytes, hipStream_t stream) {
   switch (epilogue) {
     case EPI_BF16: return launch4w<EPI_BF16>(a, nullptr, 0, stream);

@@ -158,10 +158,8 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
 
   GemmArgs p;
   p.colpart = nullptr;
-  p.gelu_lp = 0;
   p.lnf_rs = nullptr;
   p.lnf_c = nullptr;
-  p.dyn_slot = -1;
   p.raster = 0;
   p.qscale = 0.f;
   p.qcols = 0;
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(512) void gemm_tn_8phase_kernel(std::conditional_t<
   const unsigned rowoff_a = (unsigned)tl.row0 * (unsigned)p.lda * 2u, rowoff_b = (unsigned)tl.row0 * (unsigned)p.ldb * 2u;
   auto issue_loop = [&](auto kind_tag, int q, int tile) __attribute__((always_inline)) {
     constexpr int KIND = decltype(kind_tag)::value;
-    if (tile != fs.tail_tile && fs.lim[KIND] >= 0 && !(p.dbg & 8)) tn_issue_fast<KIND>(fs, q, smem, tl.sc8, rowoff_a, rowoff_b, wave_u);
+    if (tile != fs.tail_tile && fs.lim[KIND] >= 0) tn_issue_fast<KIND>(fs, q, smem, tl.sc8, rowoff_a, rowoff_b, wave_u);
     else tn_issue_part(p, q, m0, n0, kt0, smem, tl, wave_u);
   };
 
@@ -394,10 +392,8 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
                         int64_t N1, int64_t N2, float alpha, float beta) {
   GemmArgs b;
   b.colpart = nullptr;
-  b.gelu_lp = 0;
   b.lnf_rs = nullptr;
   b.lnf_c = nullptr;
-  b.dyn_slot = -1;
   b.raster = 0;
   b.qscale = 0.f;
   b.qcols = 0;
@@ -407,7 +403,7 @@ static GemmArgs tn_args(const void* dY, int64_t ldy, const void* X, int64_t ldx,
   b.alpha = alpha; b.beta = beta;
   b.tiles_m = (int)cdiv64(N1, 256);
   b.tiles_n = (int)cdiv64(N2, 256);
-  b.dbg = vj_opt(VJ_OPT_WGRAD_SLOW_ISSUE) ? 8 : 0;   // A/B switch of the K loop's issue path
+  b.dbg = 0;
   b.zero_row = nullptr;   // (the TN kernel reads the zero-initialised device global g_tn_zero_row)
   b.splitk = 1;
   b.ktiles_per = (int)cdiv64(T, 64);

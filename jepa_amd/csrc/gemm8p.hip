@@ -44,20 +44,6 @@
 
 namespace {
 
-// ---- dynamic tile hand-out (round 5, option gemm_dyn) -----------------------------------------------------------------------
-// The static lists give every workgroup of an XCD the same number of tiles.  In the two-stream step a launch rarely gets its CUs at
-// the same time -- the other stream's kernel frees them one workgroup at a time -- and a workgroup that starts late still walks its
-// full list while the CUs of the early ones go idle (or to a kernel that is not on the critical path).  Here only the first TWO tiles
-// of a workgroup are static (pos, pos + wgs_x of its XCD's band); every further tile is claimed from a per-XCD counter, two tiles
-// ahead: the claim is issued with the epilogue's other loads (it returns under the epilogue's own vmcnt(0): no new wait), handed to
-// the other seven waves through one LDS word of wave 0's staging area (idle outside the epilogue) and read after the first barrier
-// of the next tile -- early enough for that tile's tail to prefetch the claimed tile's operands.  The band order is unchanged (an
-// XCD still works on ~32 consecutive tiles of it) and every tile is computed exactly as before: outputs are bit-identical.
-// Counters: PP_DYN_SLOTS slots of 16 ints in a zero-initialised device global; a launch takes the next slot (host counter), the last
-// workgroup to finish zeroes it again; a slot is reused 1024 launches later.
-#define PP_DYN_SLOTS 1024
-__device__ int g_pp_dyn[PP_DYN_SLOTS][16];   // [slot][0..7 next tile per XCD | 8 finished workgroups]
-
 __device__ __forceinline__ void pp_bar() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);   // nothing (MFMA, ds_read, DMA issue) may be scheduled across a section boundary
@@ -72,15 +58,10 @@ __device__ __forceinline__ void pp_wait() {
 __device__ __forceinline__ unsigned pp_lds(const char* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
-// LDS-DMA, SGPR base + 32-bit lane offset form, through inline assembly (the compiler neither counts it nor assumes an LDS write)
-template <bool NT = false>
+// LDS-DMA, SGPR base + 32-bit lane offset form, through inline assembly (the compiler neither counts it nor assumes an LDS write).
+// (a non-temporal hint on the streaming operand was measured in round 5: +1.4 / +2.8 ms per step, profiles/r05_gemm_nt.md)
 __device__ __forceinline__ void pp_dma(const char* sbase, unsigned voff, unsigned lds_dst) {
-  // NT: non-temporal cache hint -- the line is the first candidate for eviction from the L2 (option gemm_nt: the operand that only
-  // STREAMS through an XCD's L2 under the current tile order, so that the panels the XCD re-uses round after round stay resident)
-  if constexpr (NT)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
-  else
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
 // the 8 wave-uniform row-group bases of one tile: A rows m0 + j*128 + mq*64, B rows n0 + j*128 + nq*32 (byte pointers at k = 0)
@@ -110,16 +91,14 @@ __device__ __forceinline__ void pp_tile_origin(const GemmArgs& p, int logical, i
 
 enum { PP_STEADY = 0, PP_HEAD0, PP_HEAD1, PP_TAIL0, PP_TAIL1 };
 
-// SCHED = 8: the round-3 schedule (four {load, compute} pairs per K-tile, 16 MFMAs per compute section);
-// SCHED = 4 (round 4): TWO pairs per K-tile, 32 MFMAs per compute section -- see k_tile4 below.
-// NTM: bit 0 = the A operand's LDS-DMA carries the non-temporal hint, bit 1 = the B operand's (option gemm_nt)
-// PRE: how an epilogue with a row operand requests it (gemm_common.hpp gemm_epilogue_staged; option gemm_epi_pre)
+// One K-tile = TWO {load section, barrier, compute section, barrier} pairs of 32 MFMAs (k_tile4 below; the four-pair schedule of round 3
+// is bit-identical and 0.3 ms per step slower: profiles/r04_abab_gemm_sched4.md).
+// PRE: form of the epilogue (gemm_common.hpp gemm_epilogue_staged; option gemm_epi_pre: 4 = pipelined passes, 0 = straight passes)
 // STAMP (diagnostics, gemm_dbg bit 2, tools/gemm_stamps.py): waves 0 and 4 (one per wave group) time the phases of every tile with
 // s_memtime -- tile start, K loop, wait for the cross-tile prefetch, epilogue, first barrier of the next tile -- and leave the sums in
 // the first bytes of C when the workgroup ends.  A kernel of its own: the product kernels carry no trace of it.
-template <int EPI, int SCHED, int NTM = 0, int PRE = 0, bool STAMP = false>
+template <int EPI, int PRE = 4, bool STAMP = false>
 __device__ __forceinline__ void pp_body(const GemmArgs& p) {
-  constexpr bool NTA = (NTM & 1) != 0, NTB = (NTM & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,21 +128,7 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   const int band0 = xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx;
   const int band_n = qx + (xcd < rx ? 1 : 0);
   const int wgs_x = (G - xcd + 7) >> 3;               // workgroups of this launch that sit on XCD `xcd`
-  const bool dyn = SCHED == 4 && p.dyn_slot >= 0;      // workgroup-uniform (kernel argument)
-  auto dyn_finish = [&]() __attribute__((always_inline)) {   // the last workgroup to leave zeroes the launch's counter slot
-    if (dyn && tid == 0) {
-      int* ctr = g_pp_dyn[p.dyn_slot];
-      const int old = __hip_atomic_fetch_add(ctr + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == (int)gridDim.x - 1) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) __hip_atomic_store(ctr + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  };
-  if (pos >= band_n) {                                // (only when there are fewer tiles than workgroups)
-    dyn_finish();
-    return;
-  }
+  if (pos >= band_n) return;                          // (only when there are fewer tiles than workgroups)
 
   const int nk = (int)(p.K / 64);
   const int64_t lda2 = p.lda * 2, ldb2 = p.ldb * 2;
@@ -185,12 +150,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     const unsigned slot = ring + (unsigned)(half * 4 + KIND) * PP_PART + dst_lane;
     const unsigned koff = (unsigned)kt * 128u;
     if constexpr (KIND == 0 || KIND == 1) {
-      pp_dma<NTB>(bs.b[KIND][0], voff_b + koff, slot);
-      pp_dma<NTB>(bs.b[KIND][1], voff_b + koff, slot + 512 * 16);
+      pp_dma(bs.b[KIND][0], voff_b + koff, slot);
+      pp_dma(bs.b[KIND][1], voff_b + koff, slot + 512 * 16);
     } else {
       constexpr int MQ = KIND == 2 ? 1 : 0;
-      pp_dma<NTA>(bs.a[MQ][0], voff_a + koff, slot);
-      pp_dma<NTA>(bs.a[MQ][1], voff_a + koff, slot + 512 * 16);
+      pp_dma(bs.a[MQ][0], voff_a + koff, slot);
+      pp_dma(bs.a[MQ][1], voff_a + koff, slot + 512 * 16);
     }
   };
   // the same for the NEXT tile (tail of the K loop, once per tile): only its two origin pointers are kept in SGPRs, the
@@ -200,12 +165,12 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     const unsigned slot = ring + (unsigned)(half * 4 + KIND) * PP_PART + dst_lane;
     const unsigned koff = (unsigned)kt * 128u;
     if constexpr (KIND == 0 || KIND == 1) {
-      pp_dma<NTB>(b0n + (int64_t)(KIND * 32) * ldb2, voff_b + koff, slot);
-      pp_dma<NTB>(b0n + (int64_t)(128 + KIND * 32) * ldb2, voff_b + koff, slot + 512 * 16);
+      pp_dma(b0n + (int64_t)(KIND * 32) * ldb2, voff_b + koff, slot);
+      pp_dma(b0n + (int64_t)(128 + KIND * 32) * ldb2, voff_b + koff, slot + 512 * 16);
     } else {
       constexpr int MQ = KIND == 2 ? 1 : 0;
-      pp_dma<NTA>(a0n + (int64_t)(MQ * 64) * lda2, voff_a + koff, slot);
-      pp_dma<NTA>(a0n + (int64_t)(128 + MQ * 64) * lda2, voff_a + koff, slot + 512 * 16);
+      pp_dma(a0n + (int64_t)(MQ * 64) * lda2, voff_a + koff, slot);
+      pp_dma(a0n + (int64_t)(128 + MQ * 64) * lda2, voff_a + koff, slot + 512 * 16);
     }
   };
   using K_B0 = std::integral_constant<int, 0>;
@@ -266,80 +231,13 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   PpBases cur;                              // wave-uniform (SGPR) row-group base pointers of the current tile
   const char *a0n = nullptr, *b0n = nullptr;   // origin pointers of the next tile
 
-  // One K-tile = four {load section, barrier, compute section, barrier}.  `t` = K-tile index inside the tile, `h` = its ring
-  // half.  MODE selects what the load sections issue and wait for (table in the header comment); everything else is the
-  // schedule of gemm8.hip.
-  auto k_tile = [&](auto mode_tag, int t, int h) __attribute__((always_inline)) {
-    constexpr int MODE = decltype(mode_tag)::value;
-    constexpr bool HEAD0 = MODE == PP_HEAD0, HEAD1 = MODE == PP_HEAD1, TAIL0 = MODE == PP_TAIL0, TAIL1 = MODE == PP_TAIL1;
-    constexpr bool TAIL0L = false, TAIL1L = false;   // (a separate no-prefetch tail is not instantiated, see below)
-    const char* half_c = smem + h * 4 * PP_PART;
-    const int ho = h ^ 1;
-    // ---------------- phase 0: rb0 <- B0(t); issue B0(t+1)
-    read_b(rb0, half_c + 0 * PP_PART);
-    if constexpr (TAIL1) {
-      issue_next(K_B0{}, a0n, b0n, 0, ho);
-      pp_wait<6>();
-    } else if constexpr (TAIL1L) {
-      pp_wait<2>();                       // B1(t) must land; only A1(t) is younger
-    } else if constexpr (!HEAD0) {
-      issue(K_B0{}, cur, t + 1, ho);
-      if constexpr (!HEAD1) pp_wait<6>();
-    }
-    pp_bar();
-    mma(Q00{}, rb0, ra0);
-    pp_bar();
-    // ---------------- phase 1: rb1 <- B1(t); issue B1(t+1)
-    read_b(rb1, half_c + 1 * PP_PART);
-    if constexpr (TAIL1) {
-      issue_next(K_B1{}, a0n, b0n, 0, ho);
-      pp_wait<6>();
-    } else if constexpr (TAIL1L) {
-      pp_wait<0>();                       // A1(t) must land; nothing is younger
-    } else if constexpr (!HEAD0) {
-      issue(K_B1{}, cur, t + 1, ho);
-      pp_wait<6>();
-    }
-    pp_bar();
-    mma(Q01{}, rb1, ra0);
-    pp_bar();
-    // ---------------- phase 2: ra1 <- A1(t); issue A1(t+1)
-    read_a(ra1, half_c + 2 * PP_PART);
-    if constexpr (TAIL1) {
-      issue_next(K_A1{}, a0n, b0n, 0, ho);
-      issue_next(K_B0{}, a0n, b0n, 1, h);           // slot (h, 0) was last read in phase 0 of this K-tile: two sections ago
-    } else if constexpr (!HEAD0 && !TAIL1L) {
-      issue(K_A1{}, cur, t + 1, ho);
-      pp_wait<6>();
-    }
-    pp_bar();
-    mma(Q11{}, rb1, ra1);
-    pp_bar();
-    // ---------------- phase 3: ra0 <- A0(t+1); issue A0(t+2)
-    if constexpr (!TAIL1 && !TAIL1L) read_a(ra0, half_c + 3 * PP_PART);
-    if constexpr (TAIL1) {
-      issue_next(K_A0{}, a0n, b0n, 1, ho);
-      issue_next(K_B1{}, a0n, b0n, 1, h);           // slot (h, 1) was last read in phase 1 of this K-tile
-    } else if constexpr (TAIL0) {
-      issue_next(K_A0{}, a0n, b0n, 0, ho);
-      pp_wait<6>();
-    } else if constexpr (TAIL0L) {
-      pp_wait<4>();                       // B0(t+1) must land; B1(t+1), A1(t+1) are younger
-    } else if constexpr (!TAIL1L) {
-      issue(K_A0{}, cur, t + 2, ho);
-      if constexpr (!HEAD0) pp_wait<6>();
-    }
-    pp_bar();
-    mma(Q10{}, rb0, ra1);
-    pp_bar();
-  };
   using M_STEADY = std::integral_constant<int, PP_STEADY>;
   using M_HEAD0 = std::integral_constant<int, PP_HEAD0>;
   using M_HEAD1 = std::integral_constant<int, PP_HEAD1>;
   using M_TAIL0 = std::integral_constant<int, PP_TAIL0>;
   using M_TAIL1 = std::integral_constant<int, PP_TAIL1>;
 
-  // ---- SCHED = 4: one K-tile = TWO {load section, barrier, compute section, barrier}:
+  // ---- one K-tile = TWO {load section, barrier, compute section, barrier}:
   //   LX(t): rb0 <- B0(t), rb1 <- B1(t);  issue A1(t+1), A0(t+2);  CX(t): quadrants 00, 01 (ra0 x rb0, rb1: 32 MFMAs)
   //   LY(t): ra1 <- A1(t), ra0 <- A0(t+1); issue B0(t+2), B1(t+2); CY(t): quadrants 11, 10 (ra1 x rb1, rb0: 32 MFMAs)
   // Why: a section boundary costs a SIMD a fixed ~80 cycles whatever the section holds (barrier release, the partner's load
@@ -411,11 +309,9 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   issue(K_B1{}, cur, 1, 1);
   pp_wait<0>();
 
-  // li_cur / li_nx: this workgroup's current and next tile, as positions in its XCD's band.  Static lists: li_nx = li_cur + wgs_x.
-  // Dynamic hand-out: the first two are static, from the third on li_nx comes out of the mailbox (claimed during the epilogue before last).
+  // li_cur / li_nx: this workgroup's current and next tile, as positions in its XCD's band (static round-robin lists: li_nx = li_cur +
+  // wgs_x; handing tiles out dynamically from per-XCD counters was built in round 5 and measured level: profiles/r05_gemm_dyn.md)
   int li_cur = pos, li_nx = pos + wgs_x;
-  volatile int* mailbox = (volatile int*)(smem + PP_RING);   // first word of wave 0's staging area
-  bool first_tile = true;
   while (true) {
 #pragma unroll
     for (int i = 0; i < 8; i++)
@@ -423,11 +319,8 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
       for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     // ---- tile start: part 6 = A1(1) -> half h^1 slot 2 (its previous content, A1 of the previous tile's last K-tile, was
     //      read >= 2 sections + one epilogue ago); every other part up to 5 landed before this wave's last vmcnt(0)
-    if constexpr (SCHED == 8) issue(K_A1{}, cur, 1, h ^ 1);   // (SCHED = 4 issues it in LX(0))
-    pp_bar();
+    pp_bar();   // (part 6 is issued by LX(0))
     lap(4, st_tiles != 0);       // [epilogue end -> past the next tile's first barrier: the skew between the eight waves]
-    if (dyn && !first_tile) li_nx = __builtin_amdgcn_readfirstlane(*mailbox);   // written by wave 0 before it arrived at the barrier above
-    first_tile = false;
     const bool has_next = li_nx < band_n;   // workgroup-uniform
     int64_t m0n, n0n;
     int tm_next;
@@ -439,22 +332,13 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     pp_bar();
     pp_bar();
     lap(0, st_tiles != 0);   // [tile start: first barrier -> K loop] (the first tile starts its clock here)
-    if constexpr (SCHED == 8) {
-      k_tile(M_HEAD0{}, 0, h);
-      k_tile(M_HEAD1{}, 1, h ^ 1);
-      int t = 2;
-      for (; t < nk - 2; t++) k_tile(M_STEADY{}, t, h ^ (t & 1));
-      // ONE tail for every tile: the last tile "prefetches" its own first parts again (never read; retired by the
-      // epilogue's vmcnt(0)).  A has_next diamond around two copies of the tail costs ~300 spilled VGPRs (hipcc 7.2).
-      k_tile(M_TAIL0{}, nk - 2, h ^ (nk & 1));
-      k_tile(M_TAIL1{}, nk - 1, h ^ ((nk - 1) & 1));
-    } else {
-      k_tile4(M_HEAD0{}, 0, h);
-      int t = 1;
-      for (; t < nk - 2; t++) k_tile4(M_STEADY{}, t, h ^ (t & 1));
-      k_tile4(M_TAIL0{}, nk - 2, h ^ (nk & 1));
-      k_tile4(M_TAIL1{}, nk - 1, h ^ ((nk - 1) & 1));
-    }
+    // ONE tail for every tile: the last tile "prefetches" its own first parts again (never read; retired by the epilogue's
+    // vmcnt(0)).  A has_next diamond around two copies of the tail costs ~300 spilled VGPRs (hipcc 7.2).
+    k_tile4(M_HEAD0{}, 0, h);
+    int t = 1;
+    for (; t < nk - 2; t++) k_tile4(M_STEADY{}, t, h ^ (t & 1));
+    k_tile4(M_TAIL0{}, nk - 2, h ^ (nk & 1));
+    k_tile4(M_TAIL1{}, nk - 1, h ^ ((nk - 1) & 1));
     if (!late_group) pp_bar();   // the early group matches the late group's extra barrier
     h ^= (nk & 1);               // ring half of the next tile's K-tile 0
     lap(1, true);                // [K loop]
@@ -473,35 +357,20 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
       const int efrow = elane & 15, efg = elane >> 4;
       pp_wait<0>();
       lap(2, true);              // [wait for the next tile's prefetched parts]
-      // dynamic hand-out: claim the tile AFTER the next one now.  Wave 0's epilogue issues the fetch-and-increment next to its bias
-      // loads (gemm_common.hpp EpiClaim): the claim's round trip hides under the wait those loads need anyway.
       // (column sums, EPI_DGELU with p.colpart: a shifted edge tile owns only its rows >= tm * 256; slot = 2 tm + wave row)
-      if constexpr (SCHED == 4) {
-        EpiClaim ec{(dyn && has_next && wave_u == 0) ? g_pp_dyn[p.dyn_slot] + xcd : nullptr, 0};
-        (void)gemm_epilogue_try_staged<EPI, 2, true, PRE>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
-                                                          smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
-                                                          tm_cur * 2 + wm, &ec);
-        if (ec.ctr != nullptr) {   // wave 0 is done with its staging area until its next epilogue
-          *mailbox = 2 * wgs_x + ec.value;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the word is in LDS before this wave arrives at the next tile's first barrier
-        }
-      } else {
-        (void)gemm_epilogue_try_staged<EPI, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
-                                               smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256,
-                                               tm_cur * 2 + wm);
-      }
+      (void)gemm_epilogue_try_staged<EPI, 2, true, PRE>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
+                                                        smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256, tm_cur * 2 + wm);
     }
     lap(3, true);                // [epilogue: bias (+ operand) latency, convert, stage, store issue]
     if constexpr (STAMP) st_tiles++;
     if (!has_next) break;
     li_cur = li_nx;
-    li_nx = li_cur + wgs_x;      // (static lists; with the dynamic hand-out the mailbox overrides it after the next barrier)
+    li_nx = li_cur + wgs_x;
     m0 = m0n;
     n0 = n0n;
     tm_cur = tm_next;
     pp_make_bases(cur, a0n, b0n, lda2, ldb2);
   }
-  dyn_finish();
   if constexpr (STAMP) {
     if (stamper && lane == 0) {   // 64 bytes per (workgroup, wave group) at the start of C (every tile's real output is older than this)
       unsigned long long* d = (unsigned long long*)p.C + ((int)blockIdx.x * 2 + (wave_u >> 2)) * 8;
@@ -514,22 +383,13 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_8phase_persist_kernel(GemmArgs p) {
-  pp_body<EPI, 8>(p);
-}
-template <int EPI, int NTM = 0>
-__global__ __launch_bounds__(512) void gemm_nt_4phase_persist_kernel(GemmArgs p) {
-  pp_body<EPI, 4, NTM>(p);
-}
 template <int EPI, int PRE>
 __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_pre_kernel(GemmArgs p) {
-  pp_body<EPI, 4, 0, PRE>(p);
+  pp_body<EPI, PRE>(p);
 }
-
-template <int EPI, int PRE>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_stamp_kernel(GemmArgs p) {
-  pp_body<EPI, 4, 0, PRE, true>(p);
+  pp_body<EPI, 4, true>(p);
 }
 
 int g_num_cus = 0;   // CU count of the (homogeneous) GPUs of this node, read once
@@ -565,7 +425,9 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   constexpr int smem = PP_RING + 8 * PP_STAGE_PER_WAVE;   // 160 KB: the whole LDS of a CU
   static VjPerDeviceOnce attr_once;   // the dynamic-LDS limit is a per-device attribute of the function
   attr_once([] {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_8phase_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   });
   GemmArgs b = a;
   b.tiles_m = (int)cdiv64(a.M, 256);
@@ -574,9 +436,6 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   b.ws = nullptr;
   b.ktiles_per = (int)(a.K / 64);
   b.raster = vj_opt(VJ_OPT_GEMM_RASTER);
-  static std::atomic<unsigned> dyn_seq{0};
-  b.dyn_slot = (vj_opt(VJ_OPT_GEMM_DYN) != 0 && vj_opt(VJ_OPT_GEMM_SCHED) == 4 && !(a.dbg & 1))
-                   ? (int)(dyn_seq.fetch_add(1, std::memory_order_relaxed) % PP_DYN_SLOTS) : -1;
   b.epi_pre = vj_opt(VJ_OPT_GEMM_EPI_PRE);
   if (b.raster == 511) {   // automatic: column groups of six for the encoder shapes (K >= 1024), the row-grouped order for the short-K predictor shapes
     b.raster = a.K >= 1024 ? 256 + 6 : 0;
@@ -595,73 +454,10 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
     if (per_xcd * 8 > g_num_cus) per_xcd = g_num_cus / 8;
     grid = (int)(per_xcd * 8);
   }
-  if (vj_opt(VJ_OPT_GEMM_SCHED) == 4) {
-    static VjPerDeviceOnce attr4_once;
-    attr4_once([] {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    });
-    // option gemm_nt: 1 = the operand that streams through an XCD's L2 carries the non-temporal hint (A under a column-grouped tile
-    // order, B under a row-grouped one); 2 = the other one (A/B control); 0 = none
-    const int ntopt = vj_opt(VJ_OPT_GEMM_NT);
-    const bool colgrouped = (b.raster & 0x100) != 0;
-    const int ntm = ntopt == 0 ? 0 : ((ntopt == 1) == colgrouped ? 1 : 2);
-    if (a.dbg & 4) {   // diagnostics: the phase-stamping copy of the default kernel (operand preload 0 or 2 as the option says)
-      static VjPerDeviceOnce attrs_once;
-      attrs_once([] {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if constexpr (EPI != EPI_GELU)
-          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, EPI == EPI_GELU ? 0 : 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if constexpr (EPI == EPI_BF16) {
-          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        }
-      });
-      if (EPI == EPI_BF16 && b.epi_pre == 5) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, EPI == EPI_BF16 ? 5 : 4>), dim3(grid), dim3(512), smem, stream, b);
-      else if (EPI == EPI_BF16 && b.epi_pre == 6) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, EPI == EPI_BF16 ? 6 : 4>), dim3(grid), dim3(512), smem, stream, b);
-      else if (b.epi_pre >= 4) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, 4>), dim3(grid), dim3(512), smem, stream, b);
-      else if (b.epi_pre == 2 && EPI != EPI_GELU) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, EPI == EPI_GELU ? 0 : 2>), dim3(grid), dim3(512), smem, stream, b);
-      else hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, b);
-      VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase, phase stamps)");
-      return 0;
-    }
-    // option gemm_epi_pre: 1 ... 3 = the kernels whose residual / dGELU epilogue requests its row operand up front (no such operand: the default
-    // kernel); 4 = the pipelined epilogue passes, every epilogue
-    constexpr bool CAN_PRE = EPI == EPI_BF16 || EPI == EPI_DGELU;
-    const bool has_opnd = EPI == EPI_DGELU ? true : (b.res != nullptr && b.lnf_rs == nullptr);
-    if (b.epi_pre >= 4 && ntm == 0) {   // (5, 6: diagnostics, stamping kernel only -- the product kernel is the pipelined one)
-      static VjPerDeviceOnce attrq_once;
-      attrq_once([] {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      });
-      hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 4>), dim3(grid), dim3(512), smem, stream, b);
-      VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase, pipelined epilogue)");
-      return 0;
-    }
-    if constexpr (CAN_PRE) {
-      if (b.epi_pre != 0 && b.epi_pre < 4 && has_opnd && ntm == 0) {
-        static VjPerDeviceOnce attrp_once;
-        attrp_once([] {
-          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        });
-        if (b.epi_pre == 1) hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 1>), dim3(grid), dim3(512), smem, stream, b);
-        else if (b.epi_pre == 2) hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 2>), dim3(grid), dim3(512), smem, stream, b);
-        else hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 3>), dim3(grid), dim3(512), smem, stream, b);
-        VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase, operand preload)");
-        return 0;
-      }
-    }
-    if (ntm == 1) hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 1>), dim3(grid), dim3(512), smem, stream, b);
-    else if (ntm == 2) hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 2>), dim3(grid), dim3(512), smem, stream, b);
-    else hipLaunchKernelGGL((gemm_nt_4phase_persist_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, b);
-  } else {
-    hipLaunchKernelGGL(gemm_nt_8phase_persist_kernel<EPI>, dim3(grid), dim3(512), smem, stream, b);
-  }
-  VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 8-phase)");
+  if (a.dbg & 4) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI>), dim3(grid), dim3(512), smem, stream, b);   // diagnostics: phase stamps
+  else if (b.epi_pre == 0) hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, b);   // A/B control
+  else hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 4>), dim3(grid), dim3(512), smem, stream, b);
+  VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 256x256)");
   return 0;
 }
 

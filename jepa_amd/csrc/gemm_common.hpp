@@ -26,15 +26,12 @@ struct GemmArgs {
   float* colpart;      // EPI_DGELU on the persistent kernel, nullable: fp32 column-sum partials of the OUTPUT, [2 * tiles_m][N]
                        // (row slot = 2 * row tile + wave row): the bias gradient of the Linear whose dY this GEMM produces
   int raster;          // persistent kernel: tile order (tile_of_raster; 0 = the default 8-row groups)
-  int gelu_lp;         // EPI_GELU: != 0 -> Phi(-|x|) = exp2(degree-6 polynomial) (common.hpp, option gelu_poly); 0 -> A-S 7.1.26
   // LayerNorm folded into this GEMM (round 5; bf16 / GELU epilogues without residual or saved derivative): A holds the RAW rows x
   // (not LayerNorm(x)), B = bf16(W * diag(gamma)), bias = b + W beta, lnf_c[n] = sum_k B[n,k] and lnf_rs[m] = {rstd_m, -mean_m * rstd_m}:
   //   out[m,n] = rstd_m * (acc[m,n] - mean_m * c[n]) + bias[n]  =  LayerNorm(x)[m,:] . W[n,:] + b[n]      (vj_gemm_bf16_nt_lnfold)
   const float* lnf_rs;   // [M][2] fp32, nullable (null: plain epilogue)
   const float* lnf_c;    // [N] fp32
-  int dyn_slot;          // persistent kernel: >= 0 -> tiles beyond the first two rounds are handed out by per-XCD atomic counters in slot
-                         // `dyn_slot` of g_pp_dyn (gemm8p.hip, option gemm_dyn); < 0 -> the static round-robin lists of rounds 3-4
-  int epi_pre = 0;       // persistent kernel: form of the epilogue (option gemm_epi_pre, options.hpp; gemm_epilogue_staged PRE below)
+  int epi_pre = 0;       // persistent kernel: form of the epilogue (option gemm_epi_pre: 4 = pipelined passes, 0 = straight passes; PRE below)
 };
 
 
@@ -221,20 +218,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, f32x4_t (&
 // rows below `row_lo` -- the part of a SHIFTED edge tile that belongs to its neighbour -- are left out) and writes the 64
 // column sums to p.colpart[slot][n_base ..]: du = dY of fc1 is produced here, so fc1's bias gradient costs 64 packed FMAs + 64
 // DPP adds per wave tile instead of a second pass over du (colsum_bf16_kernel: 84 MB per ViT-L context block).
-// Dynamic tile hand-out of the persistent kernel (gemm8p.hip): wave 0 claims a tile index from a global counter INSIDE the epilogue,
-// next to its bias loads, so that the claim's round trip and the loads' overlap under the one vmcnt(0) the epilogue has anyway.
-struct EpiClaim {
-  int* ctr;    // counter to fetch-and-increment (wave-uniform; null: no claim)
-  int value;   // out: the counter's value before the increment (valid in every lane)
-};
-
-// PRE (round 5, persistent kernel only): how the row operand (residual / saved gelu') reaches the lanes.  0: block i + 1 is requested
-// while block i is computed -- but a block is ~100 vector instructions and a load takes 0.7 ... 2 us, so the eight requests of a
-// wave tile are a CHAIN of exposed latencies, and every request issued behind a pass's stores returns only after those stores are
-// acknowledged (in-order vmcnt).  1: all eight blocks are requested next to the bias, in front of the one vmcnt(0) the epilogue has
-// anyway (64 VGPRs: the K loop's fragment registers are dead here).  2: the same bytes as sixteen row-major 16-byte loads (eight full
-// 128-byte lines per instruction instead of sixteen 32-byte pieces), parked in the staging area pass by pass and read back in the
-// MFMA layout -- the mirror image of the output path.  Same values, same arithmetic: bit-identical outputs.
+// PRE (round 5, persistent kernel only): 0 = straight passes -- the row operand (residual / saved gelu') of block i + 1 is requested while
+// block i is computed, every pass is {eight staging writes, four times {read back, wait, store}}; 4 (default) = the row operand as
+// sixteen row-major 16-byte loads issued before anything else (eight full 128-byte lines per instruction, parked in the staging area pass
+// by pass and read back in the MFMA layout -- the mirror image of the output path) and software-PIPELINED passes (see the pass loop).
+// Same values, same arithmetic: bit-identical outputs (profiles/r05_epi_pipeline.md; the intermediate forms 1 - 3 and the two
+// diagnostic copies of round 5 are recorded there).
 // NB: the launch has no bias (workgroup-uniform, resolved by the caller -- every dgrad GEMM): no bias registers (the dGELU epilogue with all its
 // row operand in flight (PRE) and sixteen column-sum accumulators is otherwise 4 VGPRs over the budget, and hipcc's spill lands between the
 // operand loads behind a vmcnt(0)) and no `+ bias` instruction (64 of a plain epilogue's ~200 vector instructions per wave tile).  Dropping
@@ -243,7 +232,7 @@ struct EpiClaim {
 template <int EPI, bool HAS_OPT, bool EDGE, int IPP, bool CSUM = false, bool QS = false, bool LP = false, bool LNF = false, int PRE = 0, bool NB = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                      int64_t n_base, int frow, int fg, int lane, char* stage,
-                                                     int64_t row_lo = 0, int slot = 0, EpiClaim* ec = nullptr) {
+                                                     int64_t row_lo = 0, int slot = 0) {
   // IPP = 16-row blocks per pass: 8 -> the whole wave tile in one 16 KB pass (stage = 16 KB per wave, the dead operand
   // ring of the one-tile-per-workgroup kernel); 2 -> four 4 KB passes (persistent kernel: the ring already holds the
   // next tile's first parts, the staging area is a separate 32 KB).
@@ -285,53 +274,30 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     }
   }
   constexpr bool HAS_OPND = (EPI == EPI_DGELU) || (EPI == EPI_BF16 && HAS_OPT);
-  // PRE 4 = PRE 3 + PIPELINED passes (see the pass loop below); also for epilogues without a row operand
-  // (PRE 5 / 6: diagnostic copies of PRE 4 for tools/gemm_stamps.py, instantiated in the stamping kernel only -- 5 issues no global store,
-  //  6 leaves out the LDS round trip and stores registers: WRONG outputs, timing only)
-  constexpr bool PIPE = PRE >= 4;
-  constexpr bool DIAG_NOST = PRE == 5, DIAG_NOLDS = PRE == 6;
-  constexpr bool PRM = HAS_OPND && (PRE == 2 || PRE == 3 || PRE >= 4);   // row operand as row-major pieces through the staging area
-  static_assert(PRE == 0 || (IPP == 2 && !EDGE && (HAS_OPND || PIPE)), "operand preload / pipelined passes: interior tiles of the persistent kernel");
+  constexpr bool PIPE = PRE >= 4;                 // pipelined passes (also for epilogues without a row operand)
+  constexpr bool PRM = HAS_OPND && PIPE;          // row operand as row-major pieces through the staging area
+  static_assert(PRE == 0 || PRE == 4, "epilogue forms: straight (0) or pipelined (4)");
+  static_assert(PRE == 0 || (IPP == 2 && !EDGE), "pipelined passes: interior tiles of the persistent kernel");
   const bf16_t* opnd_p = (EPI == EPI_DGELU) ? p.aux_in : p.res;
   const int64_t opnd_ld = (EPI == EPI_DGELU) ? p.ldaux : p.ldr;
   const int rrow = lane >> 3, rch = lane & 7;   // row-major side: 8 lanes per 128-byte row, 8 rows per instruction
-  u32x2_t opnd_all[PRE == 1 ? FM : 1][FN];      // PRE 1: the whole wave tile's operand in the MFMA layout
-  u32x4_t opnd_rm[PRM ? 2 * FM : 1];            // PRE 2: ... as sixteen row-major 16-byte pieces (rows it * 8 + rrow, chunk rch)
-  if constexpr (PRE == 1) {
+  u32x4_t opnd_rm[PRM ? 2 * FM : 1];            // the row operand as sixteen row-major 16-byte pieces (rows it * 8 + rrow, chunk rch)
+  if constexpr (PRM) {   // wave-uniform base (SGPRs, scalar arithmetic per row group) + one 32-bit lane offset: no vector address arithmetic
+    // (the row-group stride passes through an opaque asm: hipcc otherwise hoists the sixteen products it * stride out of the TILE loop
+    //  into SGPRs it then has to spill to vector lanes across the K loop)
+    int64_t ostep = opnd_ld * 16;   // 8 rows, bytes
+    asm volatile("" : "+s"(ostep));
+    const char* ob = (const char*)(opnd_p + m_base * opnd_ld + n_base);
+    const unsigned ooff = (unsigned)(rrow * (int)opnd_ld + rch * 8) * 2u;
 #pragma unroll
-    for (int i = 0; i < FM; i++) {
-      const bf16_t* base = opnd_p + (m_base + i * 16 + frow) * opnd_ld;
-#pragma unroll
-      for (int j = 0; j < FN; j++) opnd_all[i][j] = *(const u32x2_t*)(base + ncl[j]);
+    for (int it = 0; it < 2 * FM; it++) {
+      opnd_rm[it] = *(const u32x4_t*)(ob + ooff);
+      ob += ostep;
     }
   }
-  if constexpr (PRM) {
-    if constexpr (PIPE) {   // wave-uniform base (SGPRs, scalar arithmetic per row group) + one 32-bit lane offset: no vector address arithmetic
-      // (the row-group stride passes through an opaque asm: hipcc otherwise hoists the sixteen products it * stride out of the TILE loop
-      //  into SGPRs it then has to spill to vector lanes across the K loop)
-      int64_t ostep = opnd_ld * 16;   // 8 rows, bytes
-      asm volatile("" : "+s"(ostep));
-      const char* ob = (const char*)(opnd_p + m_base * opnd_ld + n_base);
-      const unsigned ooff = (unsigned)(rrow * (int)opnd_ld + rch * 8) * 2u;
-#pragma unroll
-      for (int it = 0; it < 2 * FM; it++) {
-        opnd_rm[it] = *(const u32x4_t*)(ob + ooff);
-        ob += ostep;
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 2 * FM; it++)
-        opnd_rm[it] = *(const u32x4_t*)(opnd_p + (m_base + it * 8 + rrow) * opnd_ld + n_base + rch * 8);
-    }
-  }
-  if (ec != nullptr && ec->ctr != nullptr) {   // (wave-uniform) one lane claims; the wait below covers it together with the loads above
-    int v = 0;
-    if (lane == 0) v = __hip_atomic_fetch_add(ec->ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ec->value = __builtin_amdgcn_readfirstlane(v);
-  }
-  // PRE 3 / 4 with a row operand: no blanket wait -- the compiler's own counted waits let pass ps start when ITS four operand loads (and the
-  // bias, and -- loads return in order -- every LDS-DMA issued before them) have landed, while the loads of the later passes are still in flight
-  if constexpr (!(PRM && PRE >= 3)) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
+  // with a row operand in flight there is no blanket wait: the compiler's own counted waits let pass ps start when ITS four operand loads (and
+  // the bias, and -- loads return in order -- every LDS-DMA issued before them) have landed, while the later passes' loads are still in flight
+  if constexpr (!PRM) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), compiler-visible (see gemm_epilogue_impl)
 
   // LDS addresses: write (MFMA layout) and read-back (row-major) sides of the same swizzled image
   int wr_off[FN];
@@ -459,28 +425,20 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
   };
 
   if constexpr (!PIPE) {
-    if constexpr (HAS_OPND && PRE == 0) load_row(0, opnd[0]);
+    if constexpr (HAS_OPND) load_row(0, opnd[0]);
 #pragma unroll
     for (int ps = 0; ps < FM / RPP; ps++) {
-      if constexpr (PRM) {   // this pass's operand rows: registers -> the stage image at the addresses the flush reads from
-#pragma unroll
-        for (int it = 0; it < RPP * 2; it++) *(u32x4_t*)(stage + it * 1024 + rd_off[it & 1]) = opnd_rm[ps * RPP * 2 + it];
-      }
 #pragma unroll
       for (int ii = 0; ii < RPP; ii++) {
         const int i = ps * RPP + ii;
-        if constexpr (HAS_OPND && PRE == 0) {
+        if constexpr (HAS_OPND) {
           if (i + 1 < FM) load_row(i + 1, opnd[(i + 1) & 1]);
         }
         const f32x2_t mk2 = row_mask(i);
 #pragma unroll
         for (int j = 0; j < FN; j++) {
           u32x2_t u = {0u, 0u}, o, dw;
-          if constexpr (HAS_OPND) {
-            if constexpr (PRE == 1) u = opnd_all[i][j];
-            else if constexpr (PRM) u = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);   // (this lane overwrites the same 8 bytes below)
-            else u = opnd[i & 1][j];
-          }
+          if constexpr (HAS_OPND) u = opnd[i & 1][j];
           elem(i, j, mk2, u, o, dw);
           if constexpr (TWO_OUT) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = dw;   // the saved derivative: stage blocks 0 .. RPP-1
           *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = o;
@@ -537,12 +495,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
         u32x2_t u = {0u, 0u}, o, dw;
         if constexpr (PRM) u = *(const u32x2_t*)(stage + ii * 2048 + wr_off[j]);
         elem(ii, j, mk2, u, o, dw);
-        if constexpr (DIAG_NOLDS) {
-          O[ii][j] = o;
-        } else {
-          if constexpr (TWO_OUT) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = dw;
-          *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = o;
-        }
+        if constexpr (TWO_OUT) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = dw;
+        *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = o;
       }
     }
     // output row-group pointers / strides (the strides pass through an opaque asm: hipcc otherwise turns the running pointer back into
@@ -557,8 +511,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
     auto read_back = [&](u32x4_t (&V)[NV]) __attribute__((always_inline)) {
 #pragma unroll
       for (int it = 0; it < NV; it++) {
-        if constexpr (DIAG_NOLDS) V[it] = (u32x4_t){O[it % RPP][it % FN][0], O[it % RPP][it % FN][1], O[(it + 1) % RPP][(it + 2) % FN][0], O[(it + 1) % RPP][(it + 2) % FN][1]};
-        else V[it] = *(const u32x4_t*)(stage + it * 1024 + rd_off[it & 1]);   // (two outputs: the derivative's blocks first)
+        V[it] = *(const u32x4_t*)(stage + it * 1024 + rd_off[it & 1]);   // (two outputs: the derivative's blocks first)
       }
     };
     auto store_out = [&](const u32x4_t (&V)[NV]) __attribute__((always_inline)) {
@@ -569,25 +522,18 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
         // form cost 47 of the ~300 instructions of a plain epilogue, whose time is the issue of its instructions (tools/gemm_stamps.py)
         char*& ob = (TWO_OUT && !second) ? ob_aux : ob_c;
         const unsigned ooff = (TWO_OUT && !second) ? ooff_aux : ooff_c;
-        if constexpr (DIAG_NOST) {
-          asm volatile("" ::"v"(V[it]));   // the read-back still happens and is waited for
-          if (p.M < 0) *(u32x4_t*)(ob + ooff) = V[it];
-        } else {
-          *(u32x4_t*)(ob + ooff) = V[it];
-        }
+        *(u32x4_t*)(ob + ooff) = V[it];
         ob += (TWO_OUT && !second) ? step_aux : step_c;
       }
     };
     auto put = [&]() __attribute__((always_inline)) {   // O (and Dw) -> the stage image
-      if constexpr (!DIAG_NOLDS) {
 #pragma unroll
-        for (int ii = 0; ii < RPP; ii++)
+      for (int ii = 0; ii < RPP; ii++)
 #pragma unroll
-          for (int j = 0; j < FN; j++) {
-            if constexpr (TWO_OUT) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = Dw[ii][j];
-            *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = O[ii][j];
-          }
-      }
+        for (int j = 0; j < FN; j++) {
+          if constexpr (TWO_OUT) *(u32x2_t*)(stage + ii * 2048 + wr_off[j]) = Dw[ii][j];
+          *(u32x2_t*)(stage + ((TWO_OUT ? RPP : 0) + ii) * 2048 + wr_off[j]) = O[ii][j];
+        }
     };
 #pragma unroll
     for (int ps = 0; ps < NP; ps++) {
@@ -637,7 +583,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x4_t 
 template <int EPI, int IPP = 8, bool ALLOW_LNF = true, int PRE = 0>
 __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x4_t (&acc)[8][4], int64_t m_base,
                                                          int64_t n_base, int frow, int fg, int lane, char* stage,
-                                                         int64_t row_lo = 0, int slot = 0, EpiClaim* ec = nullptr) {
+                                                         int64_t row_lo = 0, int slot = 0) {
   if constexpr (EPI == EPI_F32) {
     return false;
   } else {
@@ -653,10 +599,10 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     if constexpr (EPI == EPI_DGELU && IPP == 2) {   // persistent kernel (every tile interior): optional fused column sums
       if (p.colpart != nullptr && !edge) {
         if constexpr (PRE != 0) {   // (a dgrad GEMM has no bias; with one, the kernel that keeps bias registers)
-          if (p.bias == nullptr) gemm_epilogue_staged<EPI, true, false, IPP, true, false, false, false, PRE, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
-          else gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
+          if (p.bias == nullptr) gemm_epilogue_staged<EPI, true, false, IPP, true, false, false, false, PRE, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot);
+          else gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot);
         } else {
-          gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot, ec);
+          gemm_epilogue_staged<EPI, true, false, IPP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, row_lo, slot);
         }
         return true;
       }
@@ -665,13 +611,13 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
     // default kernels' register allocation is untouched)
     if constexpr (PRE != 0 && (EPI == EPI_DGELU || EPI == EPI_BF16) && IPP == 2) {
       if (opt && !edge && (EPI == EPI_DGELU ? p.bias == nullptr : p.lnf_rs == nullptr)) {
-        if constexpr (EPI == EPI_BF16 && PRE >= 4) {   // (pipelined form: a residual GEMM without a bias -- the dgrad that adds the skip path's gradient)
+        if constexpr (EPI == EPI_BF16) {   // (pipelined form: a residual GEMM without a bias -- the dgrad that adds the skip path's gradient)
           if (p.bias == nullptr) {
-            gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, PRE, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, PRE, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
             return true;
           }
         }
-        gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, PRE, EPI == EPI_DGELU>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+        gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, PRE, EPI == EPI_DGELU>(p, acc, m_base, n_base, frow, fg, lane, stage);
         return true;
       }
     }
@@ -679,57 +625,49 @@ __device__ __forceinline__ bool gemm_epilogue_try_staged(const GemmArgs& p, f32x
       if (p.lnf_rs != nullptr) {   // LayerNorm folded into this GEMM (workgroup-uniform; the launcher guarantees: no residual / aux_out)
         if constexpr (EPI == EPI_BF16) {
           if (p.qscale != 0.f && n_base < p.qcols) {
-            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage);
           } else {
-            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage);
           }
         } else {
-          if (p.gelu_lp) {
-            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-          } else {
-            if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-            else gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-          }
+          if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, true, XP>(p, acc, m_base, n_base, frow, fg, lane, stage);
         }
         return true;
       }
     }
     if constexpr (EPI == EPI_BF16) {
       if (p.qscale != 0.f && n_base < p.qcols) {   // wave tiles that hold q columns only (the launcher guarantees: no residual)
-        if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-        else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+        if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        else gemm_epilogue_staged<EPI, false, false, IPP, false, true, false, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage);
         return true;
       }
     }
-    if constexpr (EPI == EPI_GELU) {
-      if (p.gelu_lp) {   // workgroup-uniform (kernel argument)
-        if (opt) {
-          if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-          else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-        } else {
-          if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-          else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-        }
-        return true;
+    if constexpr (EPI == EPI_GELU) {   // GELU: Phi(-|x|) as exp2 of a degree-6 polynomial (LP = true; the Abramowitz-Stegun form of rounds 1-3 is gone)
+      if (opt) {
+        if (edge) gemm_epilogue_staged<EPI, true, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        else gemm_epilogue_staged<EPI, true, false, IPP, false, false, true, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      } else {
+        if (edge) gemm_epilogue_staged<EPI, false, true, IPP, false, false, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
+        else gemm_epilogue_staged<EPI, false, false, IPP, false, false, true, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage);
       }
-    }
-    if (opt) {
-      if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
-      else gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, EPI == EPI_DGELU ? 0 : XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);   // (dGELU WITH a bias: the straight form)
+      return true;
+    } else if (opt) {
+      if (edge) gemm_epilogue_staged<EPI, true, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
+      else gemm_epilogue_staged<EPI, true, false, IPP, false, false, false, false, EPI == EPI_DGELU ? 0 : XP>(p, acc, m_base, n_base, frow, fg, lane, stage);   // (dGELU WITH a bias: the straight form)
     } else if constexpr (EPI != EPI_DGELU) {
       if (edge) {
-        gemm_epilogue_staged<EPI, false, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+        gemm_epilogue_staged<EPI, false, true, IPP>(p, acc, m_base, n_base, frow, fg, lane, stage);
       } else {
         if constexpr (EPI == EPI_BF16 && XP >= 4) {   // (pipelined form: plain dgrad GEMMs have no bias)
           if (p.bias == nullptr) {
-            gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, false, XP, true>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+            gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, false, XP, true>(p, acc, m_base, n_base, frow, fg, lane, stage);
             return true;
           }
         }
-        gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage, 0, 0, ec);
+        gemm_epilogue_staged<EPI, false, false, IPP, false, false, false, false, XP>(p, acc, m_base, n_base, frow, fg, lane, stage);
       }
     }
     return true;
@@ -753,8 +691,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
         if (p.qscale != 0.f && n_base < p.qcols) gemm_epilogue_impl<EPI, FM, FN, false, true, false, true, false, true>(p, acc, m_base, n_base, frow, fg, slice);
         else gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
       } else {
-        if (p.gelu_lp) gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, true, true>(p, acc, m_base, n_base, frow, fg, slice);
-        else gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+        gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, true, true>(p, acc, m_base, n_base, frow, fg, slice);
       }
       return;
     }
@@ -766,19 +703,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4_t (&acc)[
       return;
     }
   }
-  if constexpr (EPI == EPI_GELU) {
-    if (p.gelu_lp) {   // workgroup-uniform (kernel argument)
-      if (opt) {
-        if (edge) gemm_epilogue_impl<EPI, FM, FN, true, true, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
-        else gemm_epilogue_impl<EPI, FM, FN, true, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
-      } else {
-        if (edge) gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
-        else gemm_epilogue_impl<EPI, FM, FN, false, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
-      }
-      return;
+  if constexpr (EPI == EPI_GELU) {   // (LP = true: the polynomial form, the only one since round 6)
+    if (opt) {
+      if (edge) gemm_epilogue_impl<EPI, FM, FN, true, true, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      else gemm_epilogue_impl<EPI, FM, FN, true, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+    } else {
+      if (edge) gemm_epilogue_impl<EPI, FM, FN, false, true, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
+      else gemm_epilogue_impl<EPI, FM, FN, false, false, false, false, true>(p, acc, m_base, n_base, frow, fg, slice);
     }
-  }
-  if (opt) {
+    return;
+  } else if (opt) {
     if (edge) gemm_epilogue_impl<EPI, FM, FN, true, true>(p, acc, m_base, n_base, frow, fg, slice);
     else gemm_epilogue_impl<EPI, FM, FN, true, false>(p, acc, m_base, n_base, frow, fg, slice);
   } else if constexpr (EPI == EPI_F32) {

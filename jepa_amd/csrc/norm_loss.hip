@@ -387,16 +387,11 @@ int vj_layernorm_bwd_partials(const void* dy_bf16, const void* x_bf16, const flo
   int64_t nb = cdiv64(rows, 16);  // >= 16 rows per workgroup so the column partials amortise
   if (nb > LN_BWD_MAX_BLOCKS) nb = LN_BWD_MAX_BLOCKS;
   if (nb < 1) nb = 1;
-  const bool pf = vj_opt(VJ_OPT_LN_BWD_PREFETCH) != 0;
-#define VJ_LNB1(NCHV, CSV, PFV)                                                                                               \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<NCHV, CSV, PFV>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16, \
+  // (PF = true: the row-ahead prefetch of round 4; its control without the prefetch is no longer instantiated: bit-identical, profiles/r04_ln_bench.txt)
+#define VJ_LNB(NCHV, CSV)                                                                                                     \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NCHV, CSV, true>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16, \
                      (const bf16_t*)x_bf16, gamma, mean, rstd, (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, (float*)ws,         \
                      rows, (int)D)
-#define VJ_LNB(NCHV, CSV)           \
-  do {                              \
-    if (pf) VJ_LNB1(NCHV, CSV, true); \
-    else VJ_LNB1(NCHV, CSV, false);   \
-  } while (0)
   if (cs) {
     if (D <= 512) VJ_LNB(1, true);
     else if (D <= 1024) VJ_LNB(2, true);
@@ -409,7 +404,6 @@ int vj_layernorm_bwd_partials(const void* dy_bf16, const void* x_bf16, const flo
     else VJ_LNB(4, false);
   }
 #undef VJ_LNB
-#undef VJ_LNB1
   VJ_LAUNCH_CHECK("vj_layernorm_bwd");
   *nb_out = nb;
   return 0;

@@ -156,12 +156,8 @@ extern "C" int vj_adamw_ema_guarded(float* p, const float* g, float* exp_avg, fl
   a.tgt_bf16 = (bf16_t*)tgt_bf16; a.n = n; a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
   a.bc1 = 1.f; a.bc2_sqrt = 1.f; a.gscale = gscale; a.ema = ema;
   a.gstat = gstat; a.sel = sel; a.clip = clip; a.norm_scale = norm_scale; a.step_dev = step_dev;
-  // option adam_grid: cap on the workgroup count (0 = 8 per CU).  Issued range by range beside the next step's forward
-  // (Trainer(overlap_update)), a full-chip grid of short workgroups keeps every CU occupied with a few waves, and a persistent
-  // GEMM workgroup needs a whole CU: a smaller grid trades update bandwidth for CUs the GEMMs can have
-  int grid = flat_grid(n / 4);
-  const int cap = vj_opt(VJ_OPT_ADAM_GRID);
-  if (cap > 0 && grid > cap) grid = cap;
+  // (a cap on the workgroup count -- fewer CUs for the update while it runs beside the next step's forward -- was an option in round 5: level)
+  const int grid = flat_grid(n / 4);
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, stream, a);
   VJ_LAUNCH_CHECK("vj_adamw_ema_guarded");
   return 0;

@@ -12,21 +12,15 @@ struct OptDef {
   const char* name;
   int dflt, lo, hi;   // accepted range (inclusive): a value outside it is rejected, never silently mapped to some kernel
 };
-// values inside [lo, hi] that still select nothing (gemm_sched: only the 4- and the 8-section kernels exist)
+// values inside [lo, hi] that still select nothing
 bool in_set(int id, int v) {
-  if (id == VJ_OPT_GEMM_SCHED) return v == 4 || v == 8;
-  if (id == VJ_OPT_ATTN_DKDV_KT) return v != 3;
-  if (id == VJ_OPT_ATTN_DQ_QW) return v == 0 || v == 2 || v == 4;
+  if (id == VJ_OPT_GEMM_EPI_PRE) return v == 0 || v == 4;
   return true;
 }
 const OptDef kDefs[VJ_OPT_COUNT] = {
-    {"gemm_fwd_flags", 0, 0, 0xffff}, {"gemm_dgrad_flags", 0, 0, 0xffff}, {"gemm_4w", 0, 0, 5},
-    {"gemm_persist", 1, 0, 2},        {"wgrad_tn", 1, 0, 1},              {"wgrad_group", 1, 0, 1},
-    {"wgrad_slow_issue", 0, 0, 1},    {"attn_dkdv_kt", 0, 0, 4},          {"gemm_dbg", 0, 0, 7},
-    {"attn_softmax", 2, 0, 2},        {"bias_fuse", 1, 0, 1},             {"gelu_poly", 1, 0, 1},
-    {"gemm_sched", 4, 4, 8},          {"attn_psum", 1, 0, 1},            {"attn_merge", 1, 0, 1},
-    {"ln_bwd_prefetch", 1, 0, 1},  {"gemm_raster", 260, 0, 511},  {"attn_dq_qw", 0, 0, 4}, {"gemm_nt", 0, 0, 2}, {"gemm_dyn", 0, 0, 1}, {"adam_grid", 0, 0, 4096}, {"ws_guard", 0, 0, 1},
-    {"gemm_epi_pre", 4, 0, 6},
+    {"gemm_fwd_flags", 0, 0, 0x1ff}, {"gemm_dgrad_flags", 0, 0, 0x1ff}, {"gemm_4w", 0, 0, 1},     {"gemm_persist", 1, 0, 2},
+    {"wgrad_tn", 1, 0, 1},           {"wgrad_group", 1, 0, 1},          {"gemm_dbg", 0, 0, 7},    {"attn_softmax", 2, 1, 2},
+    {"bias_fuse", 1, 0, 1},          {"gemm_raster", 260, 0, 511},      {"ws_guard", 0, 0, 1},    {"gemm_epi_pre", 4, 0, 4},
 };
 std::atomic<int> g_val[VJ_OPT_COUNT];
 std::once_flag g_once;

@@ -80,7 +80,6 @@ SIGNATURES = {
     "vj_attn_fwd": (I32, [P, P, P, I64, I64, I64, I64, F32, P]),
     "vj_attn_fwd_segs": (I32, [P, P, P, ctypes.POINTER(VjSeg), I64, I64, I64, F32, P]),
     "vj_attn_bwd_segs": (I32, [P, P, P, P, P, ctypes.POINTER(VjSeg), I64, I64, I64, F32, P, I64, P, P, P]),
-    "vj_attn_set_variant": (I32, [I32]),
     "vj_attn_bwd_ws_bytes": (I64, [I64, I64, I64]),
     "vj_attn_bwd_segs_ws_bytes": (I64, [ctypes.POINTER(VjSeg), I64, I64, I64]),
     "vj_attn_bwd": (I32, [P, P, P, P, P, I64, I64, I64, I64, F32, P, I64, P]),

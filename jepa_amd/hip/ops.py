@@ -164,7 +164,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, alpha=1.0,
 
 
 # ---------------------------------------------------------------- gemm
-GEMM_FLAGS = 0  # bit0: register-staged operands instead of LDS-DMA (set by tests for A/B runs)
+GEMM_FLAGS = 0  # default kernel-selection flags of vj_gemm_bf16_nt (0 = automatic; gemm.hip dispatch_gemm)
 KERNEL_TIMERS = None  # bench.py sets this to a dict: name -> list of (start_event, end_event, work) on the launch stream
 
 

@@ -32,5 +32,5 @@ def test_no_kernel_spills_vector_registers():
                 continue
             if int(spill) != 0:
                 offenders.append((base, name, int(spill)))
-    assert n_kernels >= 100, n_kernels          # 106 kernels at the end of round 3
+    assert n_kernels >= 60, n_kernels            # (106 at the end of round 3; round 6 removed the measured-negative forms)
     assert not offenders, offenders

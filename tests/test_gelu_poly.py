@@ -1,10 +1,10 @@
-"""CPU: the GELU epilogue's Phi(-|x|) = exp2(degree-6 polynomial) form (csrc/common.hpp half_erfc2_lp, option gelu_poly)
+"""CPU: the GELU epilogue's Phi(-|x|) = exp2(degree-6 polynomial) form (csrc/common.hpp half_erfc2_lp; the only form since round 6)
 checked over EVERY finite bf16 input against the erf-GELU of the reference (nn.GELU() default, src/models/utils/modules.py:32).
 
 The coefficients are read out of common.hpp, the arithmetic is restated in numpy with fp32 roundings where the kernel has them
 (FMA = one rounding, exp2 = correctly rounded here / 1 ulp on the GPU), the exact value comes from torch's float64 erf.  The
 epilogue rounds its result to bf16, so the figure of merit is how often that rounding differs from the rounding of the exact value.
-The GPU-side check of the same numbers is tests/test_round4_gpu.py::test_gelu_poly_epilogue."""
+The GPU-side check of the same numbers is tests/test_gemm_gpu.py::test_gelu_poly_epilogue."""
 import os
 import re
 

@@ -201,7 +201,7 @@ def test_vit_tiny_step_vs_oracle():
         gq = tr.arena.grad("enc.blocks.11.attn.qkv.weight").float().cpu()
         # ViT-Tiny on 8x64x64 clips at B=2 keeps ~10-20 context tokens per sample: a weight gradient is a sum over so few
         # bf16-rounded rows that the rounding noise does not average out (measured 6.0e-2 here against 6e-3..1.4e-2 on the
-        # same tensor class at ViT-L / ViT-H size, where the bound is 3e-2 for EVERY tensor: test_round2_gpu.py arena-wide)
+        # same tensor class at ViT-L / ViT-H size, where the bound is 3e-2 for EVERY tensor: test_step_fullsize_gpu.py, arena-wide)
         assert rel_l2(gq, ref["grads"]["enc"]["blocks.11.attn.qkv.weight"]) < 8e-2
         gp = tr.arena.grad("enc.patch_embed.proj.weight").float().cpu()
         assert cosine(gp, ref["grads"]["enc"]["patch_embed.proj.weight"]) > 0.99
@@ -242,7 +242,7 @@ def test_variance_regulariser_backward_vs_oracle():
     for name in ("predictor_proj.weight", "predictor_blocks.1.mlp.fc1.weight", "mask_tokens.0"):
         g = tr.arena.grad("pred." + name).float().cpu().reshape(ref["grads"]["pred"][name].shape)
         # micro model (D = 64 / 32, ~30 tokens): measured 3.6e-2 on predictor_proj.weight and 7.3e-2 on mask_tokens.0 (a sum
-        # over ~20 bf16 rows); 3e-2 is the bound at full size (every tensor: test_round2_gpu.py, arena-wide)
+        # over ~20 bf16 rows); 3e-2 is the bound at full size (every tensor: test_step_fullsize_gpu.py, arena-wide)
         assert rel_l2(g, ref["grads"]["pred"][name]) < 8e-2, (name, rel_l2(g, ref["grads"]["pred"][name]))
     g = tr.arena.grad("enc.blocks.0.attn.qkv.weight").float().cpu()
     assert cosine(g, ref["grads"]["enc"]["blocks.0.attn.qkv.weight"]) > 0.995

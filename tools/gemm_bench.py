@@ -37,9 +37,7 @@ def main():
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     from jepa_amd.hip.lib import set_option
-    # "4.0" = flags 0x100 (gemm4w.hip); "8.0" = automatic selection with the persistent 8-phase kernel (gemm8p.hip) enabled;
-    # "8.4" = the same with option gemm_sched = 4 (two section pairs of 32 MFMAs per K-tile); "9.0" = flags 0x200, the PERSISTENT
-    # two-workgroups-per-CU 4-wave kernel (round 5, gemm_nt_4wp_kernel)
+    # "4.0" = flags 0x100 (gemm4w.hip); "8.x" = automatic selection with the persistent 256x256 kernel (gemm8p.hip) enabled
     cfgs = [tuple(int(v) for v in c.split(".")) + (None,) for c in args.cfgs.split(",")]
     tvals = (0, 1)
     if args.toggle and "=" in args.toggle:
@@ -62,9 +60,8 @@ def main():
         for c, q, tg in cfgs:
             if tg is not None:
                 set_option(args.toggle, tg)
-            flags = 0x100 if c == 4 else (0x200 if c == 9 else (0 if c == 8 else (c << 4) | (q << 6)))
+            flags = 0x100 if c == 4 else (0 if c == 8 else (c << 4) | (q << 6))
             set_option("gemm_persist", 1 if c == 8 else 0)
-            set_option("gemm_sched", 4 if (c == 8 and q == 4) else 8)
 
             def run():
                 if epi == 3:

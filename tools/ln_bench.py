@@ -9,7 +9,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jepa_amd.hip import ops  # noqa: E402
-from jepa_amd.hip.lib import set_option  # noqa: E402
 
 
 def timed(fn, reps=50):
@@ -36,17 +35,8 @@ def main():
         dy = torch.randn(rows, D, device=dev).to(torch.bfloat16)
         dres = torch.randn(rows, D, device=dev).to(torch.bfloat16)
         dg, db, ds = (torch.zeros(D, device=dev) for _ in range(3))
-        outs = []
-        for pf in (0, 1):
-            set_option("ln_bwd_prefetch", pf)
-            us = timed(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres, dxsum=ds))
-            outs.append((ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres, dxsum=ds).clone(), dg.clone(), db.clone(), ds.clone()))
-            print(f"LN bwd rows={rows} D={D} prefetch={pf}: {us:6.1f} us  {rows * D * 8 / us / 1e6:5.2f} TB/s (x, dy, dres in, dx out; "
-                  f"+ reduction launch)")
-        set_option("ln_bwd_prefetch", 1)
-        same = all(torch.equal(a, c) for a, c in zip(outs[0], outs[1]))
-        print(f"   prefetch 0 / 1 outputs bit-identical: {same}")
-
+        us = timed(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres, dxsum=ds))
+        print(f"LN bwd rows={rows} D={D}: {us:6.1f} us  {rows * D * 8 / us / 1e6:5.2f} TB/s (x, dy, dres in, dx out; + reduction launch)")
 
 if __name__ == "__main__":
     main()
