@@ -85,9 +85,9 @@ int vj_layernorm_bwd_colsum(const void* dy_bf16, const void* x_bf16, const float
  *           4 bf16 out = (acc + bias) * (n < N/3 ? alpha : 1)   (the qkv projection of Attention, modules.py:63, whose q part carries
  *             the soft-max scale alpha = head_dim^-0.5 * log2(e) with ONE rounding; the attention entry points are then called with
  *             a NEGATIVE scale = "q is pre-scaled"; N % 12 == 0, no residual)
- * K % 32 == 0, N % 4 == 0, lda/ldb % 8 == 0.  flags bit0: register-staged operand path (A/B testing); bits 4-8: kernel selection
- * (0 = automatic).  The GELU epilogues (1) evaluate Phi(-|x|) as exp2 of a degree-6 polynomial (option "gelu_poly", default;
- * 0 = Abramowitz-Stegun 7.1.26): closer to the correctly rounded bf16 erf-GELU of nn.GELU() and one v_rcp + three multiplies cheaper. */
+ * K % 32 == 0, N % 4 == 0, lda/ldb % 8 == 0.  flags bits 4-8: kernel selection (0 = automatic).  The GELU epilogues (1) evaluate
+ * Phi(-|x|) as exp2 of a degree-6 polynomial: 5 of the 24 222 bf16 inputs in (-5, 2^127) round differently from the correctly
+ * rounded bf16 erf-GELU of nn.GELU() (tests/test_gelu_poly.py). */
 int vj_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M,
                     int64_t N, int64_t K, const float* bias, const void* residual, int64_t ldr, const void* aux_in,
                     void* aux_out, int64_t ldaux, int epilogue, float alpha, float beta, int flags,
@@ -179,7 +179,7 @@ int vj_attn_bwd(const void* qkv, const void* o, const void* dout, const float* l
 /* the same, plus the column sums of dqkv over this [B,S] segment as fp32 partials -- the qkv bias gradient (autograd of
  * Attention.qkv's bias, modules.py:63) from the kernels that produce dqkv instead of a second pass over it:
  * colq [rows_q][H*hd] (dQ kernel: one row per (sample, 128-query block)), colkv [rows_kv][2*H*hd] (dK/dV kernel: one row per
- * (sample, key block)); row counts from vj_attn_bwd_colsum_rows (they depend on the attn_dkdv_kt option); every element is
+ * (sample, key block)); row counts from vj_attn_bwd_colsum_rows (they depend on the head-dim class); every element is
  * written; dqkv is bit-identical to vj_attn_bwd's.  Reduce with vj_reduce_segments. */
 int vj_attn_bwd_colsum_rows(int64_t B, int64_t S, int64_t hd, int64_t* rows_q, int64_t* rows_kv);
 int vj_attn_bwd_colsum(const void* qkv, const void* o, const void* dout, const float* lse2, void* dqkv, int64_t B,
@@ -377,8 +377,9 @@ int vj_comm_destroy(vj_comm_t comm);
 /* ---- run-time tuning switches ------------------------------------------------------------------------------
  * Named integer options that choose between kernels computing the same result (A/B measurements interleaved in one
  * process, tools/abab.py): "gemm_fwd_flags", "gemm_dgrad_flags", "gemm_4w", "gemm_persist", "wgrad_tn",
- * "wgrad_group", "wgrad_slow_issue", "attn_dkdv_kt", "gemm_dbg", "attn_softmax", "bias_fuse", "gelu_poly", "gemm_sched", "attn_psum",
- * "attn_merge", "ln_bwd_prefetch", "gemm_raster", "attn_dq_qw", "gemm_nt", "gemm_dyn", "adam_grid", "ws_guard", "gemm_epi_pre" (meaning, default and accepted range of each: jepa_amd/csrc/options.hpp / options.cpp).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
+ * "wgrad_group", "gemm_dbg", "attn_softmax", "bias_fuse", "gemm_raster", "ws_guard", "gemm_epi_pre" (twelve; meaning, default
+ * and accepted values of each: jepa_amd/csrc/options.hpp / options.cpp; forms that were measured and removed live as patches
+ * under lab/patches/).  Initial value: environment variable VJ_<NAME IN UPPER CASE>, else
  * the built-in default.  Unknown names are an argument error.  The reference has no counterpart (it has no kernels). */
 int vj_set_option(const char* name, int value);
 int vj_get_option(const char* name, int* value);

@@ -135,7 +135,7 @@ struct RowTile {
 // i = lane&15) needs column d0+i of the 8 tokens {t0+4g+0..3, t0+16+4g+0..3}.  The gfx950 transpose read delivers
 // exactly that from row-major data: within a 16-lane group, lane 4j+q supplies the address of the 8-byte chunk
 // (row j, columns 4q..4q+3) and lane i receives column i of the four rows (mapping verified on hardware by
-// tests/test_kernels_gpu.py::test_probe_tr16_dump).  Two reads (rows t0.. and t0+16..) fill the 8 k-slots.
+// tests/test_rows_gpu.py::test_probe_tr16_dump).  Two reads (rows t0.. and t0+16..) fill the 8 k-slots.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 template <int HDP>
 struct TrFrag {

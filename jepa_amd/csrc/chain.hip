@@ -40,7 +40,7 @@ static inline int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
 static inline int64_t pad64i(int64_t m) { return (m + 63) / 64 * 64; }
 
 // ---------------------------------------------------------------------------------------------------- guard bands
-// Option ws_guard (diagnostics, tests/test_round5_gpu.py): every member of the two workspace layouts is followed by a 256-byte
+// Option ws_guard (diagnostics, tests/test_chain_gpu.py): every member of the two workspace layouts is followed by a 256-byte
 // gap.  A chain call fills the gaps of the workspace it was given with a byte pattern (in stream order, before its first
 // kernel) and remembers where they are; vj_ws_guard_check() synchronises the device and counts the gaps whose pattern
 // changed -- a kernel that writes past the end of a saved activation, a column-partial or a split-K buffer lands in one.

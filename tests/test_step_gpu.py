@@ -355,10 +355,5 @@ def test_vit_huge_step_vs_oracle_head_dim_80():
             assert v < 3e-2, (k, v)
 
 
-@pytest.mark.timeout(1500)
-def test_vit_large_loss_at_the_benched_batch_24():
-    """The batch bench.py times (B=24: batch-min mask truncation over 24 draws, the split-K factors of 24-clip weight
-    gradients): first-step loss within 1e-3 relative of the fp32 oracle (~3-4 min of CPU work at 64 threads)."""
-    from tests.step_util import VITL
-    rep = _big_model_step_vs_oracle(VITL, 24, n_grad_checks=False)
-    assert rep["loss_rel"] < 1e-3, rep
+# (the benched batch, B = 24, is checked against the oracle run in fp32 by eager PyTorch on the GPU -- loss and EVERY gradient tensor -- in
+#  tests/test_step_fullsize_gpu.py; the CPU-oracle loss check at that batch cost 80 - 200 s of host time and was dropped in round 6)

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--only-fwd", action="store_true")
     ap.add_argument("--shapes", default="")
     ap.add_argument("--sm", default="", help="comma list of attn_softmax option values to run one after the other (e.g. 0,1)")
-    ap.add_argument("--opts", default="", help="semicolon list of option settings to run one after the other, e.g. ';attn_dkdv_kt=4;attn_dkdv_kt=4,attn_dq_qw=4'")
+    ap.add_argument("--opts", default="", help="semicolon list of option settings to run one after the other, e.g. ';attn_softmax=1'")
     ap.add_argument("--errors", action="store_true", help="also print rel-L2 of o / dq / dk / dv against fp32 SDPA (small B)")
     args = ap.parse_args()
     dev = "cuda"

@@ -88,9 +88,9 @@ def main():
         ("prd fc2", 58368, 384, 1536, ("bias+res",)),
         ("prd dfc2", 58368, 1536, 384, ("dgelu",)),
     ]
-    # arguments: comma-separated gemm_epi_pre values, then any number of option settings "name=value" (e.g. gemm_dyn=1 gemm_persist=2),
+    # arguments: comma-separated gemm_epi_pre values, then any number of option settings "name=value" (e.g. gemm_raster=0 gemm_persist=2),
     # then optionally "only=<tag substring>"
-    pres = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["2"])]
+    pres = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["4"])]
     only = None
     for kv in sys.argv[2:]:
         k, v = kv.split("=")
