@@ -139,7 +139,7 @@ def cpu_baseline(wl_name):
     from oracle import ref_cpu_step
     wl = WORKLOADS[wl_name]
     cores = min(os.cpu_count(), 64)   # torch CPU kernels stop scaling (and thrash) far below 256 threads
-    if ref_cpu_step.available():
+    if ref_cpu_step.available() and os.environ.get("VJ_CPU_BASELINE_KIND", "") != "port":   # =port: time the oracle beside the reference
         n_timed = 3 if wl_name != "vittiny" else 10
         v, times, threads = ref_cpu_step.time_reference(wl, HP, batch=2, timed=n_timed, threads=cores, log=log)
         return {"value": round(v, 4), "unit": "clips/s", "cores": threads, "kind": "reference",
