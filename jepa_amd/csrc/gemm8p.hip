@@ -20,6 +20,14 @@
 //     loads, the K loop and the epilogue (no clamped 64-bit addressing, no predicates).  The overlap region is computed by
 //     two tiles with identical fp32 accumulation order, hence written twice with identical bits.
 //   * The epilogue is staged through a separate 32 KB of LDS (4 KB per wave, four passes) because the ring is live.
+//   * HALF TILES (round 6; a kernel of its own, gemm_nt_4phase_persist_half_kernel, launched when N % 256 == 128 with a bf16 epilogue:
+//     the predictor's N = 384 and 1152).  The shifted last column tile would recompute 128 columns its neighbour owns.  Such a tile
+//     computes its last 128 columns only, and its four live wave tiles (2 x 2 of 128 x 64) are taken by the EARLY wave group, one per
+//     SIMD, while the late group only issues its share of the LDS-DMA and meets the barriers: the intervals in which the late group
+//     would compute shrink to the early group's fragment loads, and the epilogue runs with one wave per SIMD.  Every output element
+//     still sees the same MFMA sequence over K, so results stay bit-identical; the overlap columns are written once instead of twice.
+//     A half tile costs ~0.8 of a full one (its load intervals are bound by the LDS bandwidth of the live waves' fragment reads):
+//     N = 384 launches -8 ... -12 %, the step -0.5 ms (profiles/r06_gemm_half_tiles.md).  Option gemm_persist = 3 is the A/B control.
 //
 // Section structure of one tile (h = ring half of its first K-tile; parts of K-tile t: B0, B1, A1 in half h(t) slots 0..2,
 // A0(t+1) in half h(t) slot 3):
@@ -97,7 +105,7 @@ enum { PP_STEADY = 0, PP_HEAD0, PP_HEAD1, PP_TAIL0, PP_TAIL1 };
 // STAMP (diagnostics, gemm_dbg bit 2, tools/gemm_stamps.py): waves 0 and 4 (one per wave group) time the phases of every tile with
 // s_memtime -- tile start, K loop, wait for the cross-tile prefetch, epilogue, first barrier of the next tile -- and leave the sums in
 // the first bytes of C when the workgroup ends.  A kernel of its own: the product kernels carry no trace of it.
-template <int EPI, int PRE = 4, bool STAMP = false>
+template <int EPI, int PRE = 4, bool STAMP = false, bool HALF = false>
 __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -178,22 +186,36 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   using K_A1 = std::integral_constant<int, 2>;
   using K_A0 = std::integral_constant<int, 3>;
 
-  // per-lane fragment byte offsets inside a part (rows are 128 B, chunks XOR-swizzled by row & 7)
+  // per-lane fragment byte offsets inside a part (rows are 128 B, chunks XOR-swizzled by row & 7), set per tile by set_role()
   int a_off[4][2], b_off[2][2];
+  // role of this wave in the CURRENT tile: (wm, wn) in a full tile; in a half tile the early group's waves 0..3 take the wave tiles
+  // (0,2) (0,3) (1,2) (1,3) and the late group is idle.  The offsets are re-derived from a VOLATILE lane id at every tile start so
+  // that they are dead during the epilogue (carried across it they cost the epilogue 12 VGPRs, i.e. spills).
+  int wm_t = wm, wn_t = wn;
+  bool live = true;
+  auto set_role = [&](int64_t n0_tile) __attribute__((always_inline)) {
+    const bool half = HALF && ((int)n0_tile & 255) == 128;
+    wm_t = (half && !late_group) ? ((wave_u >> 1) & 1) : wm;
+    wn_t = (half && !late_group) ? (2 + (wave_u & 1)) : wn;
+    live = !(half && late_group);
+    int tl = lane;
+    if constexpr (HALF) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tl));
+    const int fr = tl & 15, fgq = tl >> 4;
 #pragma unroll
-  for (int ks = 0; ks < 2; ks++) {
-    const int c = ks * 4 + fg;
+    for (int ks = 0; ks < 2; ks++) {
+      const int c = ks * 4 + fgq;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int pr = wm * 64 + i * 16 + frow;
-      a_off[i][ks] = pr * 128 + ((c ^ (pr & 7)) * 16);
+      for (int i = 0; i < 4; i++) {
+        const int pr = wm_t * 64 + i * 16 + fr;
+        a_off[i][ks] = pr * 128 + ((c ^ (pr & 7)) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int pr = wn_t * 32 + j * 16 + fr;
+        b_off[j][ks] = pr * 128 + ((c ^ (pr & 7)) * 16);
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int pr = wn * 32 + j * 16 + frow;
-      b_off[j][ks] = pr * 128 + ((c ^ (pr & 7)) * 16);
-    }
-  }
+  };
 
   f32x4_t acc[8][4];
   bf16x8_t ra0[4][2], ra1[4][2], rb0[2][2], rb1[2][2];  // [fragment][k-step]
@@ -251,14 +273,20 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   // read in LX(t).  Waits: a load section leaves at most the 8 youngest DMA instructions in flight (the two parts it issued and
   // the two parts of the section before): the parts the NEXT load section reads were issued before those.  K-tile 0 waits for
   // nothing (its parts and K-tile 1's landed before the epilogue's vmcnt(0)), so the previous tile's stores drain under 64 MFMAs.
-  auto k_tile4 = [&](auto mode_tag, int t, int h) __attribute__((always_inline)) {
+  // LIVE = false: the K-tile of an idle wave (late group of a half tile): its share of the LDS-DMA, the waits and the barriers only.
+  // (Built and measured level or worse, profiles/r06_gemm_half_tiles.md: the idle group issuing BOTH groups' DMA so that the early group's
+  //  load sections hold ds_reads only -- those sections are bound by the LDS bandwidth of the four live waves' fragment reads.)
+  auto k_tile4 = [&](auto mode_tag, auto live_tag, int t, int h) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool LIVE = decltype(live_tag)::value;
     constexpr bool HEAD0 = MODE == PP_HEAD0, TAIL0 = MODE == PP_TAIL0, TAIL1 = MODE == PP_TAIL1;
     const char* half_c = smem + h * 4 * PP_PART;
     const int ho = h ^ 1;
     // ---------------- LX
-    read_b(rb0, half_c + 0 * PP_PART);
-    read_b(rb1, half_c + 1 * PP_PART);
+    if constexpr (LIVE) {
+      read_b(rb0, half_c + 0 * PP_PART);
+      read_b(rb1, half_c + 1 * PP_PART);
+    }
     if constexpr (TAIL1) {
       issue_next(K_A1{}, a0n, b0n, 0, ho);
       issue_next(K_A0{}, a0n, b0n, 1, ho);
@@ -271,12 +299,16 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     }
     if constexpr (!HEAD0) pp_wait<8>();
     pp_bar();
-    mma(Q00{}, rb0, ra0);
-    mma(Q01{}, rb1, ra0);
+    if constexpr (LIVE) {
+      mma(Q00{}, rb0, ra0);
+      mma(Q01{}, rb1, ra0);
+    }
     pp_bar();
     // ---------------- LY
-    read_a(ra1, half_c + 2 * PP_PART);
-    if constexpr (!TAIL1) read_a(ra0, half_c + 3 * PP_PART);   // (the next tile's A0(0) is read at its start, after the epilogue)
+    if constexpr (LIVE) {
+      read_a(ra1, half_c + 2 * PP_PART);
+      if constexpr (!TAIL1) read_a(ra0, half_c + 3 * PP_PART);   // (the next tile's A0(0) is read at its start, after the epilogue)
+    }
     if constexpr (TAIL1) {
       issue_next(K_B0{}, a0n, b0n, 1, h);
       issue_next(K_B1{}, a0n, b0n, 1, h);
@@ -289,8 +321,10 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
     }
     if constexpr (!HEAD0 && !TAIL1) pp_wait<8>();
     pp_bar();
-    mma(Q11{}, rb1, ra1);
-    mma(Q10{}, rb0, ra1);
+    if constexpr (LIVE) {
+      mma(Q11{}, rb1, ra1);
+      mma(Q10{}, rb0, ra1);
+    }
     pp_bar();
   };
 
@@ -312,56 +346,82 @@ __device__ __forceinline__ void pp_body(const GemmArgs& p) {
   // li_cur / li_nx: this workgroup's current and next tile, as positions in its XCD's band (static round-robin lists: li_nx = li_cur +
   // wgs_x; handing tiles out dynamically from per-XCD counters was built in round 5 and measured level: profiles/r05_gemm_dyn.md)
   int li_cur = pos, li_nx = pos + wgs_x;
+  using R_LIVE = std::true_type;
+  using R_IDLE = std::false_type;
+  if constexpr (!HALF) set_role(0);   // (the kernels without half tiles keep their fragment offsets for the whole launch, as before round 6)
   while (true) {
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    // ---- tile start: part 6 = A1(1) -> half h^1 slot 2 (its previous content, A1 of the previous tile's last K-tile, was
-    //      read >= 2 sections + one epilogue ago); every other part up to 5 landed before this wave's last vmcnt(0)
-    pp_bar();   // (part 6 is issued by LX(0))
-    lap(4, st_tiles != 0);       // [epilogue end -> past the next tile's first barrier: the skew between the eight waves]
-    const bool has_next = li_nx < band_n;   // workgroup-uniform
+    if constexpr (HALF) set_role(n0);
+    bool has_next;                          // workgroup-uniform
     int64_t m0n, n0n;
     int tm_next;
-    pp_tile_origin(p, band0 + (has_next ? li_nx : li_cur), m0n, n0n, tm_next);
-    a0n = (const char*)(p.A + m0n * p.lda);
-    b0n = (const char*)(p.B + n0n * p.ldb);
-    if (late_group) pp_bar();
-    read_a(ra0, smem + ((h ^ 1) * 4 + 3) * PP_PART);   // L(-1): A0(0)
-    pp_bar();
-    pp_bar();
-    lap(0, st_tiles != 0);   // [tile start: first barrier -> K loop] (the first tile starts its clock here)
-    // ONE tail for every tile: the last tile "prefetches" its own first parts again (never read; retired by the epilogue's
-    // vmcnt(0)).  A has_next diamond around two copies of the tail costs ~300 spilled VGPRs (hipcc 7.2).
-    k_tile4(M_HEAD0{}, 0, h);
-    int t = 1;
-    for (; t < nk - 2; t++) k_tile4(M_STEADY{}, t, h ^ (t & 1));
-    k_tile4(M_TAIL0{}, nk - 2, h ^ (nk & 1));
-    k_tile4(M_TAIL1{}, nk - 1, h ^ ((nk - 1) & 1));
-    if (!late_group) pp_bar();   // the early group matches the late group's extra barrier
-    h ^= (nk & 1);               // ring half of the next tile's K-tile 0
-    lap(1, true);                // [K loop]
+    auto next_origin = [&]() __attribute__((always_inline)) {   // (behind the tile's first barrier, where it has always been)
+      has_next = li_nx < band_n;
+      pp_tile_origin(p, band0 + (has_next ? li_nx : li_cur), m0n, n0n, tm_next);
+      a0n = (const char*)(p.A + m0n * p.lda);
+      b0n = (const char*)(p.B + n0n * p.ldb);
+    };
+    // The diamond is around the WHOLE tile (nothing wide is live across it: accumulators and fragments belong to the live side);
+    // branches around single sections made hipcc spill several hundred VGPRs.
+    auto compute_tile = [&](auto role_tag) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      // ---- tile start: part 6 = A1(1) -> half h^1 slot 2 (its previous content, A1 of the previous tile's last K-tile, was
+      //      read >= 2 sections + one epilogue ago); every other part up to 5 landed before this wave's last vmcnt(0)
+      pp_bar();   // (part 6 is issued by LX(0))
+      lap(4, st_tiles != 0);       // [epilogue end -> past the next tile's first barrier: the skew between the eight waves]
+      next_origin();
+      if (late_group) pp_bar();
+      read_a(ra0, smem + ((h ^ 1) * 4 + 3) * PP_PART);   // L(-1): A0(0)
+      pp_bar();
+      pp_bar();
+      lap(0, st_tiles != 0);   // [tile start: first barrier -> K loop] (the first tile starts its clock here)
+      // ONE tail for every tile: the last tile "prefetches" its own first parts again (never read; retired by the epilogue's
+      // vmcnt(0)).  A has_next diamond around two copies of the tail costs ~300 spilled VGPRs (hipcc 7.2).
+      k_tile4(M_HEAD0{}, role_tag, 0, h);
+      for (int t = 1; t < nk - 2; t++) k_tile4(M_STEADY{}, role_tag, t, h ^ (t & 1));
+      k_tile4(M_TAIL0{}, role_tag, nk - 2, h ^ (nk & 1));
+      k_tile4(M_TAIL1{}, role_tag, nk - 1, h ^ ((nk - 1) & 1));
+      if (!late_group) pp_bar();   // the early group matches the late group's extra barrier
+      lap(1, true);                // [K loop]
 
-    // ---- epilogue: staged through this wave's private 4 KB (the ring holds the next tile's parts).  Its first action
-    //      (bias loads + s_waitcnt vmcnt(0)) also retires every LDS-DMA this wave has issued.
-    if (p.dbg & 1) {   // diagnostics: no output traffic (keeps the accumulators alive through one predicated store)
-      pp_wait<0>();
-      if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 0.5f) *(float*)p.C = acc[3][2][1];
+      // ---- epilogue: staged through this wave's private 4 KB (the ring holds the next tile's parts).  Its first action
+      //      (bias loads + s_waitcnt vmcnt(0)) also retires every LDS-DMA this wave has issued.
+      if (p.dbg & 1) {   // diagnostics: no output traffic (keeps the accumulators alive through one predicated store)
+        pp_wait<0>();
+        if (acc[0][0][0] == 12345.678f && acc[7][3][3] == 0.5f) *(float*)p.C = acc[3][2][1];
+      } else {
+        // lane id re-derived through a VOLATILE asm: everything the epilogue computes from it (LDS staging offsets, row /
+        // column addresses) is then re-computed per tile instead of being hoisted out of the tile loop, where it would
+        // sit in VGPRs across the K loop (the K loop owns all 256)
+        int elane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
+        const int efrow = elane & 15, efg = elane >> 4;
+        pp_wait<0>();
+        lap(2, true);              // [wait for the next tile's prefetched parts]
+        // (column sums, EPI_DGELU with p.colpart: a shifted edge tile owns only its rows >= tm * 256; slot = 2 tm + wave row)
+        (void)gemm_epilogue_try_staged<EPI, 2, true, PRE>(p, acc, m0 + wm_t * 128, n0 + wn_t * 64, efrow, efg, elane,
+                                                          smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256, tm_cur * 2 + wm_t);
+      }
+      lap(3, true);                // [epilogue: bias (+ operand) latency, convert, stage, store issue]
+    };
+    if (!HALF || live) {
+      compute_tile(R_LIVE{});
     } else {
-      // lane id re-derived through a VOLATILE asm: everything the epilogue computes from it (LDS staging offsets, row /
-      // column addresses) is then re-computed per tile instead of being hoisted out of the tile loop, where it would
-      // sit in VGPRs across the K loop (the K loop owns all 256)
-      int elane;
-      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
-      const int efrow = elane & 15, efg = elane >> 4;
+      // idle wave of a half tile (always of the late group): the late group's four tile-start barriers, its DMA share, the waits
+      pp_bar();
+      next_origin();
+      pp_bar();
+      pp_bar();
+      pp_bar();
+      k_tile4(M_HEAD0{}, R_IDLE{}, 0, h);
+      for (int t = 1; t < nk - 2; t++) k_tile4(M_STEADY{}, R_IDLE{}, t, h ^ (t & 1));
+      k_tile4(M_TAIL0{}, R_IDLE{}, nk - 2, h ^ (nk & 1));
+      k_tile4(M_TAIL1{}, R_IDLE{}, nk - 1, h ^ ((nk - 1) & 1));
       pp_wait<0>();
-      lap(2, true);              // [wait for the next tile's prefetched parts]
-      // (column sums, EPI_DGELU with p.colpart: a shifted edge tile owns only its rows >= tm * 256; slot = 2 tm + wave row)
-      (void)gemm_epilogue_try_staged<EPI, 2, true, PRE>(p, acc, m0 + wm * 128, n0 + wn * 64, efrow, efg, elane,
-                                                        smem + PP_RING + wave_u * PP_STAGE_PER_WAVE, (int64_t)tm_cur * 256, tm_cur * 2 + wm);
     }
-    lap(3, true);                // [epilogue: bias (+ operand) latency, convert, stage, store issue]
+    h ^= (nk & 1);               // ring half of the next tile's K-tile 0
     if constexpr (STAMP) st_tiles++;
     if (!has_next) break;
     li_cur = li_nx;
@@ -390,6 +450,10 @@ __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_pre_kernel(GemmArg
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_4phase_persist_stamp_kernel(GemmArgs p) {
   pp_body<EPI, 4, true>(p);
+}
+// the kernel with half tiles (N % 256 == 128; bf16 epilogues only: the predictor's proj / fc2 / dgrad / qkv GEMMs)
+__global__ __launch_bounds__(512) void gemm_nt_4phase_persist_half_kernel(GemmArgs p) {
+  pp_body<EPI_BF16, 4, false, true>(p);
 }
 
 int g_num_cus = 0;   // CU count of the (homogeneous) GPUs of this node, read once
@@ -428,6 +492,8 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_pre_kernel<EPI, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_stamp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if constexpr (EPI == EPI_BF16)
+      (void)hipFuncSetAttribute((const void*)gemm_nt_4phase_persist_half_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   });
   GemmArgs b = a;
   b.tiles_m = (int)cdiv64(a.M, 256);
@@ -437,6 +503,8 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
   b.ktiles_per = (int)(a.K / 64);
   b.raster = vj_opt(VJ_OPT_GEMM_RASTER);
   b.epi_pre = vj_opt(VJ_OPT_GEMM_EPI_PRE);
+  // half tiles (N % 256 == 128, bf16 epilogues, pipelined form): a kernel of its own, so that every other launch runs the code it ran before
+  b.half_tiles = (EPI == EPI_BF16 && a.N % 256 == 128 && b.epi_pre != 0 && vj_opt(VJ_OPT_GEMM_PERSIST) != 3 && !(a.dbg & 4)) ? 1 : 0;
   if (b.raster == 511) {   // automatic: column groups of six for the encoder shapes (K >= 1024), the row-grouped order for the short-K predictor shapes
     b.raster = a.K >= 1024 ? 256 + 6 : 0;
   }
@@ -452,9 +520,14 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
     const int64_t band = cdiv64(tiles, 8);                  // tiles of the largest XCD band
     int64_t per_xcd = cdiv64(band, rounds);
     if (per_xcd * 8 > g_num_cus) per_xcd = g_num_cus / 8;
+    // half tiles cost ~0.6 of a full tile and alternate with full tiles in the order when there are two column tiles (N = 384): a
+    // workgroup takes every per_xcd-th tile of its band, so an ODD stride hands everybody both kinds
+    if (b.half_tiles && b.tiles_n == 2 && (per_xcd & 1) == 0 && per_xcd > 1) per_xcd += per_xcd * 8 < g_num_cus ? 1 : -1;
     grid = (int)(per_xcd * 8);
   }
-  if (a.dbg & 4) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI>), dim3(grid), dim3(512), smem, stream, b);   // diagnostics: phase stamps
+  if (b.half_tiles) {
+    if constexpr (EPI == EPI_BF16) hipLaunchKernelGGL(gemm_nt_4phase_persist_half_kernel, dim3(grid), dim3(512), smem, stream, b);
+  } else if (a.dbg & 4) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI>), dim3(grid), dim3(512), smem, stream, b);   // diagnostics: phase stamps
   else if (b.epi_pre == 0) hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 0>), dim3(grid), dim3(512), smem, stream, b);   // A/B control
   else hipLaunchKernelGGL((gemm_nt_4phase_persist_pre_kernel<EPI, 4>), dim3(grid), dim3(512), smem, stream, b);
   VJ_LAUNCH_CHECK("vj_gemm_bf16_nt(persistent 256x256)");

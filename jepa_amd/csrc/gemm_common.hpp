@@ -31,6 +31,7 @@ struct GemmArgs {
   //   out[m,n] = rstd_m * (acc[m,n] - mean_m * c[n]) + bias[n]  =  LayerNorm(x)[m,:] . W[n,:] + b[n]      (vj_gemm_bf16_nt_lnfold)
   const float* lnf_rs;   // [M][2] fp32, nullable (null: plain epilogue)
   const float* lnf_c;    // [N] fp32
+  int half_tiles = 0;    // persistent kernel: N % 256 == 128 and the shifted last column tile computes its own 128 columns only (gemm8p.hip)
   int epi_pre = 0;       // persistent kernel: form of the epilogue (option gemm_epi_pre: 4 = pipelined passes, 0 = straight passes; PRE below)
 };
 

@@ -279,15 +279,9 @@ def test_persistent_gemm_tile_orders_are_bit_identical(ops, M, N, K):
 
 
 # ------------------------------------------------------------------------------------------ pipelined epilogue passes
-@pytest.mark.timeout(300)
-@pytest.mark.parametrize("M,N,K", [(37632, 1152, 256), (5000, 1296, 256), (10560, 1536, 1088), (2304 + 40, 2592, 320), (58560, 384, 384)])
-def test_pipelined_epilogue_is_bit_identical(ops, M, N, K):
-    """Option gemm_epi_pre = 4 (default): the persistent kernel's epilogue passes are software-pipelined (the row-major read-back of pass ps is in
-    flight while the arithmetic of pass ps + 1 runs; a row operand is parked and re-read for the next pass behind the issued reads).
-    Every epilogue the persistent kernel has -- plain / bias / residual, the q-column scale, GELU with one and two outputs, dGELU with
-    and without the fused column sums, the folded LayerNorm -- must give the bits of the straight form (option 0, the A/B control), also
-    on shifted edge tiles and with the full grid."""
-    g = torch.Generator(device=DEV).manual_seed(67)
+def _epilogue_suite(ops, M, N, K, seed=67):
+    """A callable that runs EVERY epilogue the persistent kernel has on one (M, N, K) problem and returns the outputs."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
     A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
     W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device=DEV, generator=g)
@@ -313,12 +307,23 @@ def test_pipelined_epilogue_is_bit_identical(ops, M, N, K):
         outs.append(ops.gemm_nt_lnfold(A, Wf, bfold, rs, cvec))
         du, colpart = ops.gemm_dgelu_colsum(A, W, aux)
         outs.append(du)
-        if colpart is not None:
-            outs.append(colpart)
+        outs.append(colpart)   # None when the column sums were not fused (one-tile kernel)
         outs.append(ops.gemm_nt(A, W, aux_in=aux, epilogue=ops.EPI_DGELU))
         outs.append(ops.gemm_nt(A, W, bias=bias, aux_in=aux, epilogue=ops.EPI_DGELU))
         torch.cuda.synchronize()
         return outs
+    return run_all
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("M,N,K", [(37632, 1152, 256), (5000, 1296, 256), (10560, 1536, 1088), (2304 + 40, 2592, 320), (58560, 384, 384)])
+def test_pipelined_epilogue_is_bit_identical(ops, M, N, K):
+    """Option gemm_epi_pre = 4 (default): the persistent kernel's epilogue passes are software-pipelined (the row-major read-back of pass ps is in
+    flight while the arithmetic of pass ps + 1 runs; a row operand is parked and re-read for the next pass behind the issued reads).
+    Every epilogue the persistent kernel has -- plain / bias / residual, the q-column scale, GELU with one and two outputs, dGELU with
+    and without the fused column sums, the folded LayerNorm -- must give the bits of the straight form (option 0, the A/B control), also
+    on shifted edge tiles and with the full grid."""
+    run_all = _epilogue_suite(ops, M, N, K)
     with _opt("gemm_epi_pre", 0):
         ref = run_all()
     for persist in (1, 2):
@@ -327,6 +332,39 @@ def test_pipelined_epilogue_is_bit_identical(ops, M, N, K):
                 got = run_all()
                 assert len(got) == len(ref)
                 for i, (a, b) in enumerate(zip(ref, got)):
+                    assert (a is None) == (b is None), (persist, rep, i)
+                    assert a is None or torch.equal(a, b), (persist, rep, i, int((a != b).sum()))
+
+
+# ------------------------------------------------------------------------------------------ half tiles (N % 256 == 128)
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("M,N,K", [(58560, 384, 1536), (52800 + 8, 384, 384), (53760, 384, 1152), (3000, 384, 320), (256, 384, 256),
+                                   (4000 + 24, 1152, 384)])
+def test_half_tiles_are_bit_identical_to_full_tiles(ops, M, N, K):
+    """Round 6: when N = 384 the shifted second column tile of the persistent kernel computes only the 128 columns it owns, on the
+    early wave group (one wave per SIMD) while the late group idles through the barriers (N = 1152 keeps full tiles: control case).  Every epilogue must give the bits of the
+    form that recomputes the overlap (option gemm_persist = 3, the A/B control) and of the one-tile kernel (gemm_persist = 0), with the
+    trimmed and the full grid, on odd and even K-tile counts and with a shifted last ROW tile as well; outputs start as NaN, so a
+    column nobody wrote would show."""
+    run_all = _epilogue_suite(ops, M, N, K, seed=71)
+    with _opt("gemm_persist", 3):
+        ref = run_all()
+    with _opt("gemm_persist", 0):
+        one = run_all()
+    for i, (a, b) in enumerate(zip(ref, one)):
+        assert a is None or b is None or torch.equal(a, b), ("one-tile kernel", i, int((a != b).sum()))
+    for persist in (1, 2):
+        with _opt("gemm_persist", persist):
+            for rep in range(2):
+                got = None
+                poison = [torch.full_like(t, float("nan")) for t in ref if t is not None]   # the allocator hands run_all() these blocks next
+                del poison
+                got = run_all()
+                for i, (a, b) in enumerate(zip(ref, got)):
+                    assert (a is None) == (b is None), (persist, rep, i)
+                    if a is None:
+                        continue
+                    assert not torch.isnan(b.float()).any(), (persist, rep, i, "unwritten output")
                     assert torch.equal(a, b), (persist, rep, i, int((a != b).sum()))
 
 

@@ -58,10 +58,10 @@ def main():
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
         res = []
         for c, q, tg in cfgs:
-            if tg is not None:
-                set_option(args.toggle, tg)
             flags = 0x100 if c == 4 else (0 if c == 8 else (c << 4) | (q << 6))
             set_option("gemm_persist", 1 if c == 8 else 0)
+            if tg is not None:
+                set_option(args.toggle, tg)      # (after the line above: --cfgs 8.0 --toggle gemm_persist=3,1 compares forms of the persistent kernel)
 
             def run():
                 if epi == 3:
