@@ -482,7 +482,7 @@ def main():
             next(fcsv)
             for ln in fcsv:
                 f_, tag, m, n, k, us = ln.split(",")[:6]
-                if f_ == "0" and tag == "0":
+                if f_ == "0" and tag == "0" and int(n) % 256 != 128:   # (N % 256 == 128 runs gemm_nt_4phase_persist_half_kernel since round 6)
                     m, n, k = int(m), int(n), int(k)
                     dom["launches"] += 1
                     dom["ms"] += float(us) * 1e-3
@@ -502,7 +502,7 @@ def main():
         # correction + WRITE_SIZE), committed under profiles/ -- counters cannot be collected from inside this process
         DOM = "gemm_nt_4phase_persist_pre_kernel<0, 4>"
         traffic, traffic_src = None, None
-        for pmc_name in ("r05_hbm_pmc.json", "r04_hbm_pmc.json"):   # newest first (round 5: taken at HEAD with the column-grouped tile order)
+        for pmc_name in ("r06_hbm_pmc.json", "r05_hbm_pmc.json", "r04_hbm_pmc.json"):   # newest first
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc) and args.workload == "vitl16":
                 with open(pmc) as fjs:
@@ -522,7 +522,7 @@ def main():
                 "traffic": traffic, "traffic_unit": f"HBM bytes per launch of {DOM} (PMC)", "traffic_source": traffic_src,
                 "whole_step": whole,
                 "gemm_family": {"kernels": "gemm_nt_4phase_persist_pre_kernel<0|1|2, 4> (persistent 256x256 NT, two staggered wave groups, two "
-                                           "32-MFMA sections per K-tile, cross-tile LDS-DMA prefetch, pipelined epilogue), gemm_tn_8phase_kernel "
+                                           "32-MFMA sections per K-tile, cross-tile LDS-DMA prefetch, pipelined epilogue; N % 256 == 128: gemm_nt_4phase_persist_half_kernel), gemm_tn_8phase_kernel "
                                            "(transpose-free weight gradients, the four of a block in one launch); MFMA 16x16x32 bf16",
                                 "achieved": round(ach / 1e12, 2), "frac": round(ach / MFMA_BF16_PEAK, 4),
                                 "launches_per_step": g["launches"] // n_inst,
