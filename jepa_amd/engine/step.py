@@ -137,6 +137,10 @@ _UPD_LOW_PRIO = _os.environ.get("VJ_UPD_LOW_PRIO", "0") == "1"   # the deferred 
 # GEMM kernel selection of the EMA target encoder's forward (vj_blocks_fwd gemm_flags: low 16 bits = flags, bits 16-23 = first
 # block they apply to); 0 = automatic everywhere
 _TGT_GEMM_FLAGS = int(_os.environ.get("VJ_TGT_GEMM_FLAGS", "0"), 0)
+# the same for the predictor trunk (A/B measurements: tools/abab.py pred_flags / pred_dgrad_flags; 0 = the automatic selection):
+# forward through vj_blocks_fwd's gemm_flags, backward by setting option gemm_dgrad_flags around the predictor's backward chain only
+_PRED_GEMM_FLAGS = int(_os.environ.get("VJ_PRED_GEMM_FLAGS", "0"), 0)
+_PRED_DGRAD_FLAGS = int(_os.environ.get("VJ_PRED_DGRAD_FLAGS", "0"), 0)
 
 
 def _strip(name):
@@ -289,7 +293,7 @@ class Trainer:
                 h = self.forward_target(cl, mp)
             z, segs, saved_e = encoder_forward(self.ew, cl, me, save=True, ws_tag=self._ws + "enc_save", gates=self._gate("enc"))
             zhat, tsegs, saved_p = predictor_forward(self.pw, z, segs, me, mp, save=True, ws_tag=self._ws + "pred_save",
-                                                     gates=self._gate("pred"))
+                                                     gemm_flags=_PRED_GEMM_FLAGS, gates=self._gate("pred"))
             mark('context+predictor forward (main stream)')
             if fwd_overlap:
                 side.join()
@@ -319,8 +323,13 @@ class Trainer:
             if last:
                 self.reducer.begin(side.stream if side.enabled else None)
             lhook = hook if last else None
+            if _PRED_DGRAD_FLAGS:
+                from ..hip.lib import set_option
+                old_dg = set_option("gemm_dgrad_flags", _PRED_DGRAD_FLAGS)
             dz = predictor_backward(dzhat, saved_p, self.pw, segs, alpha, on_layer_done=lhook, beta=beta,
                                     ws_tag=self._ws + "bwd_tmp")
+            if _PRED_DGRAD_FLAGS:
+                set_option("gemm_dgrad_flags", old_dg)
             mark('predictor backward (main stream)')
             encoder_backward(dz, saved_e, self.ew, segs, alpha, on_layer_done=lhook, beta=beta,
                              ws_tag=self._ws + "bwd_tmp")

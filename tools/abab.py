@@ -10,7 +10,8 @@ per-arm median / min ms per step and the paired per-round delta against arm 0 (m
     python tools/abab.py --arms "base;4w:gemm_4w=1;tn:wgrad_tn=1" --rounds 6 --steps 6
 host-side switches:  no_overlap=1 (single stream), overlap_fwd=0 (target forward on the main stream), upd_overlap=0 (the fused
                      AdamW / EMA update on the main stream, as rounds 1-4 ran it), ln_fold=1 (the target encoder's LayerNorms folded into its qkv / fc1 GEMMs),
-                     tgt_flags=F (GEMM selection of the target encoder: flags | first block << 16, e.g. 786688 = 0x100 from block 12)
+                     tgt_flags=F (GEMM selection of the target encoder: flags | first block << 16, e.g. 786688 = 0x100 from block 12),
+                     pred_flags=F / pred_dgrad_flags=F (the same for the predictor's forward / backward chain, e.g. 256 = the 4-wave kernel)
 """
 import argparse
 import json
@@ -44,7 +45,7 @@ def parse_arms(spec):
     return arms
 
 
-HOST_SWITCHES = ("no_overlap", "overlap_fwd", "tgt_flags", "upd_overlap", "upd_prio", "ln_fold")
+HOST_SWITCHES = ("no_overlap", "overlap_fwd", "tgt_flags", "pred_flags", "pred_dgrad_flags", "upd_overlap", "upd_prio", "ln_fold")
 
 
 def main():
@@ -91,6 +92,8 @@ def main():
             torch.cuda.synchronize()
             step_mod._UPD_LOW_PRIO, trainer._upd_stream, trainer._upd_lowp = lowp, None, lowp   # fused update on its own stream, range by range (Trainer(overlap_update=))
         step_mod._TGT_GEMM_FLAGS = int(opts.get("tgt_flags", 0))   # vj_blocks_fwd gemm_flags of the target encoder (flags | first block << 16)
+        step_mod._PRED_GEMM_FLAGS = int(opts.get("pred_flags", 0))        # the same for the predictor's forward chain
+        step_mod._PRED_DGRAD_FLAGS = int(opts.get("pred_dgrad_flags", 0))  # option gemm_dgrad_flags around the predictor's backward chain only
 
     def run_steps(n, first=0):
         # every block runs the SAME batches (first, first+1, ...): mask sizes differ by batch and move the step time by
