@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """LayerNorm forward / backward micro-benchmark on the step's row counts (HBM-bound: bytes moved / time).
-Backward = the chains' variant (dx + residual gradient in, column partials of dgamma | dbeta | dx, one reduction launch), measured
-with option ln_bwd_prefetch = 0 and 1."""
+Backward = the chains' variant (dx + residual gradient in, column partials of dgamma | dbeta | dx, one reduction launch)."""
 import os
 import sys
 
