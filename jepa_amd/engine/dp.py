@@ -133,7 +133,12 @@ class GradReducer:
         if (self.coll_mode == "sync" and self._capi is None and os.environ.get("VJ_DP_VERIFY", "1") != "0"
                 and dist.get_backend() == "nccl"):
             self.coll_check = self.verify_collective_stream()
-            if self.coll_check["verdict"] == "other-stream":
+            # the ranks decide TOGETHER (building the C-ABI communicator is itself a collective): any rank that saw its collectives on
+            # another stream moves every rank to the capi route
+            flag = torch.tensor([1.0 if self.coll_check["verdict"] == "other-stream" else 0.0], device=self.arena.G.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            self.coll_check["any_rank_other_stream"] = bool(flag.item() > 0)
+            if self.coll_check["any_rank_other_stream"]:
                 import warnings
                 warnings.warn("jepa_amd: torch.distributed launched a blocking collective on a stream of its own instead of the current "
                               f"(communication) stream ({self.coll_check}); switching the gradient buckets to the C-ABI route (vj_comm_*), "
@@ -164,19 +169,33 @@ class GradReducer:
         'unobserved': the collectives produced no device activity (a one-rank in-place all-reduce is a no-op) -- nothing to disprove."""
         from ..hip.lib import check, load_library
         out = {"verdict": "unavailable", "marker_stream": None, "collective_streams": [], "activities": []}
+        lib = load_library()
+        dev = self.arena.G.device
+        t = torch.ones(4096, dtype=torch.float32, device=dev)
+        g = torch.empty(4096 * max(1, dist.get_world_size()), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        # The two collectives below are issued on EVERY rank whatever happens to the tracer on this one: a rank that skipped them
+        # would leave the others waiting.  Tracing is best effort around them.
+        prof = None
         try:
             from torch.profiler import ProfilerActivity, profile
-            lib = load_library()
-            dev = self.arena.G.device
-            t = torch.ones(4096, dtype=torch.float32, device=dev)
-            g = torch.empty(4096 * max(1, dist.get_world_size()), dtype=torch.float32, device=dev)
-            torch.cuda.synchronize(dev)
-            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-                check(lib.vj_probe_spin(1000, self.comm_stream.cuda_stream), "vj_probe_spin")   # 10 us marker on the comm stream
-                with torch.cuda.stream(self.comm_stream):
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                    dist.all_gather_into_tensor(g, t)
-                torch.cuda.synchronize(dev)
+            prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+            prof.__enter__()
+        except Exception as ex:   # no tracer in this build / a tracer already attached (rocprofv3)
+            out["error"] = f"{type(ex).__name__}: {ex}"[:200]
+            prof = None
+        try:
+            check(lib.vj_probe_spin(1000, self.comm_stream.cuda_stream), "vj_probe_spin")   # 10 us marker on the comm stream
+        except Exception as ex:
+            out["error"] = f"{type(ex).__name__}: {ex}"[:200]
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(g, t)
+        torch.cuda.synchronize(dev)
+        if prof is None:
+            return out
+        try:
+            prof.__exit__(None, None, None)
             marker, colls = None, []
             for e in prof.events():
                 if str(e.device_type).endswith("CPU"):
@@ -195,7 +214,7 @@ class GradReducer:
                 out["verdict"] = "unobserved"
             else:
                 out["verdict"] = "comm-stream" if all(sid == marker for _, sid in colls) else "other-stream"
-        except Exception as ex:   # no tracer in this build / a tracer already attached (rocprofv3): keep the route, say so
+        except Exception as ex:
             out["error"] = f"{type(ex).__name__}: {ex}"[:200]
         return out
 
