@@ -509,22 +509,22 @@ static int launch8p(const GemmArgs& a, hipStream_t stream) {
     b.raster = a.K >= 1024 ? 256 + 6 : 0;
   }
   const int64_t tiles = (int64_t)b.tiles_m * b.tiles_n;
-  // Grid: the tile count is fixed, so the kernel takes `rounds` = ceil(tiles / CUs) tile times whatever the grid is; the
-  // SMALLEST grid that still needs only `rounds` tiles per workgroup leaves the other CUs to the step's second stream for
-  // the whole launch instead of idling them in a ragged last round (588 tiles: 200 workgroups x 3 tiles, 56 CUs free,
-  // rather than 256 workgroups of which 180 run a third tile).  Equal workgroup counts per XCD keep the bands balanced.
-  // Option gemm_persist = 2 launches one workgroup per CU regardless (A/B).
-  int grid = g_num_cus;
+  // Grid: one workgroup per CU (option gemm_persist = 2, the default since late round 6).  Rounds 3 - 6 launched the SMALLEST grid that still needs
+  // only `rounds` = ceil(tiles / CUs) tiles per workgroup (588 tiles: 200 workgroups x 3 tiles, 56 CUs left to the step's second stream for the
+  // whole launch; option value 1): re-measured at the end of round 6 the full grid is 0.2 ms per step faster in 9 of 10 interleaved rounds
+  // (profiles/r06_abab_grid.md) -- the workgroups that run out of tiles a round early leave the last round to fewer CUs at a higher clock.
+  // Equal workgroup counts per XCD keep the bands balanced.
+  int64_t per_xcd = g_num_cus / 8;
   if (vj_opt(VJ_OPT_GEMM_PERSIST) != 2) {
     const int64_t rounds = cdiv64(tiles, g_num_cus);
     const int64_t band = cdiv64(tiles, 8);                  // tiles of the largest XCD band
-    int64_t per_xcd = cdiv64(band, rounds);
+    per_xcd = cdiv64(band, rounds);
     if (per_xcd * 8 > g_num_cus) per_xcd = g_num_cus / 8;
-    // half tiles cost ~0.6 of a full tile and alternate with full tiles in the order when there are two column tiles (N = 384): a
-    // workgroup takes every per_xcd-th tile of its band, so an ODD stride hands everybody both kinds
-    if (b.half_tiles && b.tiles_n == 2 && (per_xcd & 1) == 0 && per_xcd > 1) per_xcd += per_xcd * 8 < g_num_cus ? 1 : -1;
-    grid = (int)(per_xcd * 8);
   }
+  // half tiles cost ~0.8 of a full tile and alternate with full tiles in the order when there are two column tiles (N = 384): a
+  // workgroup takes every per_xcd-th tile of its band, so an ODD stride hands everybody both kinds
+  if (b.half_tiles && b.tiles_n == 2 && (per_xcd & 1) == 0 && per_xcd > 1) per_xcd += per_xcd * 8 < g_num_cus ? 1 : -1;
+  const int grid = (int)(per_xcd * 8);
   if (b.half_tiles) {
     if constexpr (EPI == EPI_BF16) hipLaunchKernelGGL(gemm_nt_4phase_persist_half_kernel, dim3(grid), dim3(512), smem, stream, b);
   } else if (a.dbg & 4) hipLaunchKernelGGL((gemm_nt_4phase_persist_stamp_kernel<EPI>), dim3(grid), dim3(512), smem, stream, b);   // diagnostics: phase stamps

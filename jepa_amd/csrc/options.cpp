@@ -18,7 +18,7 @@ bool in_set(int id, int v) {
   return true;
 }
 const OptDef kDefs[VJ_OPT_COUNT] = {
-    {"gemm_fwd_flags", 0, 0, 0x1ff}, {"gemm_dgrad_flags", 0, 0, 0x1ff}, {"gemm_4w", 0, 0, 1},     {"gemm_persist", 1, 0, 3},
+    {"gemm_fwd_flags", 0, 0, 0x1ff}, {"gemm_dgrad_flags", 0, 0, 0x1ff}, {"gemm_4w", 0, 0, 1},     {"gemm_persist", 2, 0, 3},
     {"wgrad_tn", 1, 0, 1},           {"wgrad_group", 1, 0, 1},          {"gemm_dbg", 0, 0, 7},    {"attn_softmax", 2, 1, 2},
     {"bias_fuse", 1, 0, 1},          {"gemm_raster", 260, 0, 511},      {"ws_guard", 0, 0, 1},    {"gemm_epi_pre", 4, 0, 4},
 };

@@ -15,7 +15,8 @@ enum VjOpt {
   VJ_OPT_GEMM_DGRAD_FLAGS,     // ... for the chains' dgrad GEMMs
   VJ_OPT_GEMM_4W,              // 1: every forward / dgrad GEMM on the 4-wave 256x128 kernel with two workgroups per CU (gemm4w.hip: faster on a single
                                // stream -- frozen-encoder inference --, 1.2 - 5.4 % slower in the two-stream training step); 0 (default): automatic
-  VJ_OPT_GEMM_PERSIST,         // 1 (default): persistent 256x256 kernel (gemm8p.hip) where it applies, trimmed grid; 2: one workgroup per CU;
+  VJ_OPT_GEMM_PERSIST,         // persistent 256x256 kernel (gemm8p.hip) where it applies: 2 (default since late round 6): one workgroup per CU; 1: the smallest
+                               // grid that keeps the number of tile rounds (rounds 3 - 6: left CUs to the other stream; -0.2 ms for 2 now, 9 of 10 rounds);
                                // 3: as 1, but N % 256 == 128 launches recompute the overlap instead of running half tiles (A/B control of round 6);
                                // 0: always one tile per workgroup (gemm8.hip) -- the bit-identity control of the persistent kernel
   VJ_OPT_WGRAD_TN,             // 1 (default): transpose-free weight gradients (gemm8_tn.hip); 0: transposes + NT split-K GEMM (the cross-check route)

@@ -59,7 +59,7 @@ def main():
         res = []
         for c, q, tg in cfgs:
             flags = 0x100 if c == 4 else (0 if c == 8 else (c << 4) | (q << 6))
-            set_option("gemm_persist", 1 if c == 8 else 0)
+            set_option("gemm_persist", 2 if c == 8 else 0)
             if tg is not None:
                 set_option(args.toggle, tg)      # (after the line above: --cfgs 8.0 --toggle gemm_persist=3,1 compares forms of the persistent kernel)
 
