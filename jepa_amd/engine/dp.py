@@ -173,6 +173,9 @@ class GradReducer:
         dev = self.arena.G.device
         t = torch.ones(4096, dtype=torch.float32, device=dev)
         g = torch.empty(4096 * max(1, dist.get_world_size()), dtype=torch.float32, device=dev)
+        with torch.cuda.stream(self.comm_stream):   # (builds the communicator OUTSIDE the traced region: connection set-up is not what is checked)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.fill_(1.0)
         torch.cuda.synchronize(dev)
         # The two collectives below are issued on EVERY rank whatever happens to the tracer on this one: a rank that skipped them
         # would leave the others waiting.  Tracing is best effort around them.
